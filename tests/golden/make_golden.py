@@ -1,0 +1,256 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the REFERENCE's own functions.
+
+Runs only in the build container, where the read-only reference checkout is
+mounted at /root/reference.  It imports the reference's unmodified
+`homography.py` and `ransac.py` (their one missing dependency, OpenCV, is
+satisfied by an empty stub module: no hot-path function touches cv2) and
+records inputs + outputs as plain, pickle-free numpy arrays.  No reference
+source text is written anywhere; the fixtures are data only.
+
+Usage:  python tests/golden/make_golden.py            (writes next to this file)
+
+Fixture IDs follow SURVEY.md section 8(c): G1..G8.
+"""
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = os.environ.get("RWH_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+sys.dont_write_bytecode = True
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+sys.path.insert(0, REF)
+import homography as ref_h  # noqa: E402  (the reference)
+import ransac as ref_r      # noqa: E402  (the reference)
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+def decode(jpg):
+    from PIL import Image
+    return np.asarray(Image.open(os.path.join(REF, jpg)).convert("RGB"), dtype=np.uint8).copy()
+
+
+def digest(prefix, img, rng, nsample=20000):
+    """Summary of a big output: shape, dtype-independent sha256 of the raw
+    bytes, per-channel sums, and `nsample` (flat index, value) pairs."""
+    flat = img.reshape(-1)
+    pick = np.sort(rng.choice(flat.size, size=min(nsample, flat.size), replace=False))
+    return {
+        prefix + "_shape": np.array(img.shape, dtype=np.int64),
+        prefix + "_sha256": np.array(sha(img)),
+        prefix + "_chansum": img.reshape(-1, img.shape[2]).sum(axis=0, dtype=np.float64),
+        prefix + "_pick": pick.astype(np.int64),
+        prefix + "_vals": flat[pick].copy(),
+    }
+
+
+# ---------------------------------------------------------------- inputs ----
+U0 = np.array([[50, 470, 600., 90], [50, 40, 300., 360], [1, 1, 1, 1.]])
+V0 = np.array([[0, 400, 400., 0], [0, 0, 780., 780], [1, 1, 1, 1]])
+H_BENCH = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+H_NOTEBOOK = np.array([[7.92272362e-01, 8.22117652e-02, 4.34671442e+02],
+                       [-1.33501977e-01, 9.58413827e-01, 6.55962640e+01],
+                       [-2.09248580e-04, 1.60937718e-05, 1.00000000e+00]])
+# scanner target for an A4 page, app-style: box=(h,w)=(1188,840)
+V_A4 = np.array([[0, 840, 840., 0], [0, 0, 1188., 1188], [1, 1, 1, 1]])
+
+
+def g1():
+    u, v = U0.T[:, :2], V0.T[:, :2]
+    A, b = ref_h.calc_correspLinear(u, v)
+    mat = ref_h.calc_corresp(u, v)
+    save("g1_fourpoint", u=U0, v=V0, A=A, b=b, mat=mat,
+         H_linear=ref_h.calcHomographyLinear(u, v),
+         H_dlt=ref_h.calcHomography(u, v),
+         # float32 inputs exercise the float32-product path of the builders
+         mat_f32in=ref_h.calc_corresp(u.astype(np.float32), v.astype(np.float32)),
+         H_dlt_f32in=ref_h.calcHomography(u.astype(np.float32), v.astype(np.float32)))
+
+
+def load_matches():
+    a = np.load(os.path.join(REF, "matchespoints.npy"), allow_pickle=True).tolist()
+    return np.ascontiguousarray(a["ptsA"], dtype=np.float32), np.ascontiguousarray(a["ptsB"], dtype=np.float32)
+
+
+def per_hypothesis(ptsA, ptsB, seed, K, th):
+    X, Y = ptsA.T, ptsB.T
+    np.random.seed(seed)
+    idx = np.random.randint(0, X.shape[1], (K, 4))
+    model = ref_r.HomoModel(th=th, d=70, n=4)
+    Hs = np.empty((K, 9), np.float32)
+    counts = {m: np.empty(K, np.int16) for m in ("fwd", "backward", "reproj")}
+    for i in range(K):
+        val = model.fit(X[:, idx[i]], Y[:, idx[i]])
+        assert val.dtype == np.float32
+        Hs[i] = val.reshape(9)
+        for m in counts:
+            counts[m][i] = np.sum(model.computeLoss(X, Y, m) < th)
+    return idx.astype(np.int32), Hs, counts
+
+
+def g2_g3(ptsA, ptsB):
+    X, Y = ptsA.T, ptsB.T
+    for name, seed in (("g2_hyp_seed0", 0), ("g3_hyp_seed7", 7)):
+        idx, Hs, counts = per_hypothesis(ptsA, ptsB, seed, 10000, 5)
+        c = counts["fwd"].astype(np.int64)
+        win = int(np.argmax(c))
+        model = ref_r.HomoModel(th=5, d=70, n=4)
+        model.val = Hs[win].reshape(3, 3)
+        err = model.computeLoss(X, Y, "fwd")
+        save(name, seed=np.int64(seed), idx=idx, H=Hs,
+             counts_fwd=counts["fwd"], counts_backward=counts["backward"], counts_reproj=counts["reproj"],
+             degenerate=np.array([len(set(r)) < 4 for r in idx.tolist()]),
+             winner=np.int64(win), winner_count=np.int64(c[win]),
+             winner_ties=np.int64(np.sum(c == c[win])),
+             winner_inliers=np.where(err < 5)[0].astype(np.int64),
+             winner_err=err.astype(np.float32))
+
+
+def run_ref_ransac(ptsA, ptsB, seed, th, d, k, method):
+    np.random.seed(seed)
+    model = ref_r.HomoModel(th=th, d=d, n=4)
+    H, inl, cnt = ref_r.RANSAC(model, k=k).run([ptsA.T, ptsB.T], method=method)
+    return np.asarray(H, np.float64), inl[0].astype(np.int64), np.int64(cnt)
+
+
+def g4_g5(ptsA, ptsB):
+    out = {}
+    # G4: ransac.example0 parameters; G5: app.py panorama parameters; GE: early-exit cases
+    cases = [("g4", s, 5, 70, 1000, m) for s in (0, 1, 2) for m in ("fwd", "backward", "reproj")]
+    cases += [("g5", 0, 4, 95, 1500, "fwd")]
+    cases += [("ge", s, 5, 50, 1000, "fwd") for s in (0, 3)] + [("ge", 1, 5, 40, 1000, "reproj")]
+    names = []
+    for tag, seed, th, d, k, m in cases:
+        H, inl, cnt = run_ref_ransac(ptsA, ptsB, seed, th, d, k, m)
+        key = "%s_s%d_th%d_d%d_k%d_%s" % (tag, seed, th, d, k, m)
+        names.append(key)
+        out[key + "_H"] = H
+        out[key + "_inliers"] = inl
+        out[key + "_count"] = cnt
+        print(key, int(cnt))
+    out["cases"] = np.array(names)
+    save("g4_ransac_runs", **out)
+
+
+def small_images():
+    rng = np.random.default_rng(1234)
+    noise = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
+    yy, xx = np.mgrid[0:60, 0:80]
+    ramp = np.stack([(xx * 255 // 79), (yy * 255 // 59), ((xx + yy) * 255 // 138)], axis=2).astype(np.uint8)
+    return {"noise": noise, "ramp": ramp}
+
+
+def g6():
+    u, v = U0.T[:, :2], V0.T[:, :2]
+    Hs = {"bench": H_BENCH, "g1lin": ref_h.calcHomographyLinear(u, v), "notebook": H_NOTEBOOK,
+          # a rotation + zoom: source footprint of an output tile is a tilted quad
+          "rot": np.array([[1.2 * np.cos(0.5), -1.2 * np.sin(0.5), 40.0],
+                           [1.2 * np.sin(0.5), 1.2 * np.cos(0.5), -10.0],
+                           [3e-4, -2e-4, 1.0]])}
+    out = {"H_names": np.array(list(Hs))}
+    for hn, H in Hs.items():
+        out["H_" + hn] = H
+    for iname, img in small_images().items():
+        out["img_" + iname] = img
+        for hn, H in Hs.items():
+            for conv in ("nn", "bilinear"):
+                o, mx, my = ref_h.wrapPerspective(img.copy(), H, convert=conv)
+                k = "wp_%s_%s_%s" % (iname, hn, conv)
+                out[k] = o
+                out[k + "_org"] = np.array([mx, my], np.int64)
+            o, mx, my = ref_h.transformImageH(img.copy(), H)
+            out["tih_%s_%s" % (iname, hn)] = o
+        # boundary=1 clamps the origin at 0
+        o, mx, my = ref_h.wrapPerspective(img.copy(), Hs["rot"], convert="bilinear", boundary=1)
+        out["wpb_%s_rot_bilinear" % iname] = o
+        out["wpb_%s_rot_bilinear_org" % iname] = np.array([mx, my], np.int64)
+        # fixed-resolution scan warps (bounds use res, which must not exceed the source)
+        hs, ws, _ = img.shape
+        for conv in ("nn", "bilinear"):
+            for hn in ("bench", "rot"):
+                res = (hs - 8, ws - 16)
+                o, _, _ = ref_h.wrapPerspectiveScan(img.copy(), Hs[hn], res, convert=conv)
+                out["scan_%s_%s_%s" % (iname, hn, conv)] = o
+        # 4-channel float32 image (constant-rate alpha), both interpolators
+        rgba = ref_h.addAlpha(img.copy(), method="Rate", rate=0.2)
+        out["rgba_" + iname] = rgba
+        for conv in ("nn", "bilinear"):
+            o, mx, my = ref_h.wrapPerspective(rgba.copy(), Hs["notebook"], convert=conv)
+            out["wp4_%s_notebook_%s" % (iname, conv)] = o
+    save("g6_small_warps", **out)
+
+
+def g7():
+    rng = np.random.default_rng(7)
+    img = decode("notebook.jpg")
+    u, v = U0.T[:, :2], V0.T[:, :2]
+    H = ref_h.calcHomographyLinear(u, v)
+    out = {"H": H, "u": U0, "v": V0, "v_a4": V_A4}
+    o, mx, my = ref_h.wrapPerspective(img.copy(), H, convert="bilinear")
+    out.update(digest("wp_bilinear", o, rng)); out["wp_bilinear_org"] = np.array([mx, my], np.int64)
+    o, mx, my = ref_h.wrapPerspective(img.copy(), H, convert="nn")
+    out.update(digest("wp_nn", o, rng))
+    o = ref_h.transformImage(img.copy(), U0, V0)
+    out.update(digest("ti", o, rng))
+    o = ref_h.transformImage(img.copy(), U0, V0, method="nn")
+    out.update(digest("ti_nn", o, rng))
+    # scanner mode, app.py:350-359 with the A4 preset: box=(h,w)=(1188,840).  The
+    # inverse map sends the box back inside the clicked quad, so the source being
+    # smaller than `res` does not trip the reference's IndexError here.
+    o = ref_h.transformImage(img.copy(), U0, V_A4, box=[1188, 840])
+    out.update(digest("scan_a4", o, rng))
+    o = ref_h.transformImage(img.copy(), U0, V_A4, box=[1188, 840], method="nn")
+    out.update(digest("scan_a4_nn", o, rng))
+    save("g7_notebook", **out)
+    save("img_notebook", img=img)
+
+
+def g8():
+    rng = np.random.default_rng(8)
+    A = decode("foto1A.jpg")
+    B = decode("foto1B.jpg")
+    out = {"H_notebook": H_NOTEBOOK}
+    o, mx, my = ref_h.transformImageH(A.copy(), H_NOTEBOOK)
+    out.update(digest("tih", o, rng)); out["tih_org"] = np.array([mx, my], np.int64)
+    o = ref_h.stitchPanorama(B.copy(), A.copy(), H_NOTEBOOK)
+    out.update(digest("stitch_paste", o, rng))
+    o = ref_h.stitchPanorama(B.copy(), A.copy(), H_NOTEBOOK, blending="Rate", blendrate=0.2)
+    out.update(digest("stitch_rate", o, rng))
+    # with the G5 RANSAC homography (app.py parameters, seed 0)
+    ptsA, ptsB = load_matches()
+    H5, _, _ = run_ref_ransac(ptsA, ptsB, 0, 4, 95, 1500, "fwd")
+    out["H_g5"] = H5
+    o = ref_h.stitchPanorama(B.copy(), A.copy(), H5, blending="Rate", blendrate=0.2)
+    out.update(digest("stitch_g5_rate", o, rng))
+    save("g8_stitch", **out)
+    save("img_foto1", A=A, B=B)
+
+
+def main():
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8"}
+    ptsA, ptsB = load_matches()
+    save("matchespoints", ptsA=ptsA, ptsB=ptsB)
+    if "g1" in which: g1()
+    if "g2" in which: g2_g3(ptsA, ptsB)
+    if "g4" in which: g4_g5(ptsA, ptsB)
+    if "g6" in which: g6()
+    if "g7" in which: g7()
+    if "g8" in which: g8()
+
+
+if __name__ == "__main__":
+    main()
