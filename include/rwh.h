@@ -1,0 +1,145 @@
+/*
+ * rwh.h -- C ABI of librwh_hip.so: MI355X (gfx950) kernels for the
+ * RANSAC-homography + backward-warp hot path of choice17/ransac_with_homography.
+ *
+ * The reference is pure Python/numpy and has no FFI of its own; the boundary a
+ * maintainer would bind (ctypes) is the set of numpy calls on its hot path.
+ * Each entry point below names the reference lines it replaces.  All pointers
+ * named `d_*` are DEVICE pointers; everything else is host memory read before
+ * the function returns.  `stream` is a hipStream_t (NULL = default stream).
+ * Functions enqueue work and return without synchronising; they allocate
+ * nothing and keep no state, so they may be captured into a hipGraph.
+ *
+ * Return value: 0 on success, a negative RWH_E_* code otherwise (never throws).
+ */
+#ifndef RWH_H
+#define RWH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RWH_ABI_VERSION 1
+#define RWH_API __attribute__((visibility("default")))
+
+enum {
+    RWH_OK = 0,
+    RWH_E_INVALID = -1,      /* bad argument (NULL pointer, size <= 0, unknown enum) */
+    RWH_E_UNSUPPORTED = -2,  /* valid but not implemented combination (dtype / channels) */
+    RWH_E_LAUNCH = -3        /* HIP reported a launch / memset failure */
+};
+
+/* element types of image planes */
+enum { RWH_U8 = 0, RWH_F32 = 1, RWH_F64 = 2 };
+/* interpolators: reference homography.py:140 `convertfunc` keys */
+enum { RWH_NEAREST = 0, RWH_BILINEAR = 1 };
+/* RANSAC loss: reference ransac.py:84-98 `computeLoss` method */
+enum { RWH_LOSS_FWD = 0, RWH_LOSS_BACKWARD = 1, RWH_LOSS_REPROJ = 2 };
+
+/* flags for rwh_warp_backward */
+#define RWH_WARP_ZERO_ORIGIN 1u /* write zeros into texel (0,0) of every source image first, exactly
+                                   like homography.py:112-116 / 126-130 do to the caller's array */
+
+RWH_API int rwh_abi_version(void);
+RWH_API const char* rwh_strerror(int code);
+
+/*
+ * Backward perspective warp.  Replaces, per call, the body of
+ *   wrapPerspective      homography.py:166-179  (grid -> inv(H) -> divide -> interpolate)
+ *   wrapPerspectiveScan  homography.py:197-208
+ *   nearestNeighbor      homography.py:108-121
+ *   bilinear             homography.py:123-138
+ * and, with dst_dtype == RWH_U8 on a bilinear warp, the `astype(np.uint8)`
+ * truncation of transformImage / transformImageH (homography.py:225, 240-241).
+ *
+ * Source: `batch` images of src_h x src_w x channels, element type src_dtype,
+ * rows contiguous, image b at d_src + b*src_image_stride (bytes).
+ * Output pixel (r, c) of the full out_h x out_w grid sits at output coordinate
+ *   x = (c == out_w-1 ? x_last : x0 + c*step_x),  y likewise
+ * (numpy.linspace semantics, homography.py:166-167 / 197-198); its source
+ * coordinate is inv_h (row-major 3x3, float64, = numpy.linalg.inv(H) computed by
+ * the caller as in homography.py:172) applied to (x, y, 1) and dehomogenised in
+ * float64.  Coordinates outside [0, bound_w-1] x [0, bound_h-1] give 0
+ * (homography.py:117-118 / 131-132; scan mode passes the OUTPUT resolution here,
+ * homography.py:208).  bound_w/bound_h are clipped to the source size.
+ * Bilinear weights come from the float64 fraction; the blend itself runs in
+ * float32 (tolerance vs the float64 reference: 1e-4 relative, typ. 3e-7).
+ *
+ * Only rows [row_begin, row_end) are produced; d_dst points at row `row_begin`
+ * of image 0 and image b at d_dst + b*dst_image_stride (bytes).  This is the
+ * unit of multi-GPU sharding (output-row tiles or images; no collective).
+ *
+ * Supported: channels 3 or 4; src_dtype U8 or F32; dst_dtype == src_dtype for
+ * RWH_NEAREST; dst_dtype U8 (truncating) or F32 for RWH_BILINEAR.
+ * n_h is 1 (one homography for the whole batch) or `batch` (inv_h holds batch
+ * 3x3 matrices, image b uses the b-th; at most RWH_MAX_H_PER_CALL).
+ */
+#define RWH_MAX_H_PER_CALL 1
+RWH_API int rwh_warp_backward(const void* d_src, int src_h, int src_w, int channels, int src_dtype,
+                      int64_t src_image_stride, int batch,
+                      const double* inv_h, int n_h,
+                      double x0, double step_x, double x_last,
+                      double y0, double step_y, double y_last,
+                      int out_h, int out_w, int bound_h, int bound_w, int interp,
+                      void* d_dst, int dst_dtype, int64_t dst_image_stride,
+                      int row_begin, int row_end, unsigned flags, void* stream);
+
+/*
+ * Batched 4-point DLT hypothesis generator.  Replaces K calls of
+ *   HomoModel.fit(X[:,idx], Y[:,idx])   ransac.py:178-180 -> 52
+ *   calcHomography / calc_corresp        homography.py:71-88 / 4-14
+ * d_pts_a, d_pts_b: M x 2 float32 (the `matchespoints` layout, points in rows);
+ * d_idx: K x 4 int32 sample indices in [0, M) (drawn by the caller from numpy's
+ * legacy generator for parity, ransac.py:177);
+ * d_h: K x 9 float32, row-major 3x3 with h[8] == 1;
+ * d_flags: K bytes, bit 0 = repeated index in the sample, bit 1 = non-finite
+ * result (singular system).  The 8x9 system is built from float32-rounded
+ * products like the reference, solved in float64, scaled to unit norm, rounded
+ * to float32 and divided by its 9th element in float32.
+ */
+#define RWH_HYP_REPEATED 1u
+#define RWH_HYP_SINGULAR 2u
+RWH_API int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m,
+                     const int32_t* d_idx, int k,
+                     float* d_h, uint8_t* d_flags, void* stream);
+
+/*
+ * Hypothesis x correspondence reprojection-error inlier scorer.  Replaces, per
+ * hypothesis,
+ *   computeLoss(X, Y, method)           ransac.py:182 -> 84-98 (fwd 55-64, reproj 66-76, dist 78-82)
+ *   inliers_pos = err < th ; np.sum     ransac.py:183-184
+ * and the accept rules of ransac.py:186-202 in order-independent form.
+ * One wavefront scores one hypothesis: lanes stride over the M correspondences,
+ * `err < th` is ballotted and popcounted.
+ * d_counts: K int32.  d_masks: optional (may be NULL) K x ceil(M/64) uint64
+ * inlier bitmasks (bit j of word w = correspondence 64*w + j).
+ * d_best: 2 x uint64, accumulated with atomic max, so several calls (hypothesis
+ * shards, `hyp_base` = global index of row 0) may share it after ONE memset:
+ *   word 0 = (count << 32) | (0xFFFFFFFF - global_index)  -> max count, lowest index on ties
+ *   word 1 = 0xFFFFFFFF - (lowest global_index with count >= need), 0 if none
+ * which is also the payload of the one RCCL all-reduce(max) in the sharded run.
+ * `th` is compared as (double)err < th.
+ * d_err: optional (may be NULL) K x M float32, the per-correspondence loss itself
+ * (what HomoModel.computeLoss returns, ransac.py:84-98).
+ */
+RWH_API int rwh_score_count(const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
+                    double th, int loss, int need, int64_t hyp_base,
+                    int32_t* d_counts, uint64_t* d_masks, uint64_t* d_best, float* d_err, void* stream);
+
+/*
+ * Project M points through one homography.  Replaces HomoModel.fwd (ransac.py:55-64,
+ * inverse == 0) and HomoModel.reproj (ransac.py:66-76, inverse != 0: through the
+ * float64 inverse rounded to float32).  d_h: 9 float32; d_pts: M x 2 float32;
+ * d_out: 3 x M float32 = (val @ [x;y;1]) / (row2 + 1e-10), same rounding recipe as
+ * rwh_score_count.
+ */
+RWH_API int rwh_project_points(const float* d_h, const float* d_pts, int m, int inverse,
+                       float* d_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RWH_H */

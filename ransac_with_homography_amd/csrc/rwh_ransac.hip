@@ -1,0 +1,298 @@
+// K1 (batched 4-point DLT) and K2 (hypothesis x correspondence inlier scorer) for gfx950.
+//
+// K1 replaces K calls of HomoModel.fit -> calcHomography -> calc_corresp + numpy SVD
+// (ransac.py:178-180, 52; homography.py:71-88, 4-14); K2 replaces computeLoss + `err < th` +
+// np.sum and the accept rules (ransac.py:182-202).  Contract in include/rwh.h.
+//
+// Numerical recipes (re-verified against tests/golden):
+//  K1  the 8x9 matrix entries are float32 (products x*x' etc. rounded to float32 like the
+//      reference's float32 inputs give); its null vector is computed in float64, scaled to unit
+//      2-norm, rounded to float32 and divided by its 9th element in float32 -- the same
+//      roundings numpy applies to LAPACK's float64 singular vector.  The float64 solve uses the
+//      block structure of the DLT matrix (both row families share the 4x3 block [-x -y -1]):
+//      one pivoted elimination of that block applied to both right-hand blocks, a 2x2 system
+//      for (h31, h32), two back substitutions.  ~100 float64 operations instead of an 8x8 LU.
+//  K2  per output row j of val @ [x;y;1] (OpenBLAS sgemm k-order):  acc = h[j,0]*x (rounded),
+//      acc = fmaf(h[j,1], y, acc), acc = acc + h[j,2];  den = acc2 + 1e-10f;  IEEE divides;
+//      s = dx*dx + dy*dy with separately rounded products;  err = sqrtf(s);  inlier = err < th.
+//      'backward' does the same through inv(val) (float64 inverse rounded to float32).
+// No FMA contraction anywhere (rwh_common.h), no fast-math, IEEE divide / sqrt.
+#include "rwh_common.h"
+
+namespace rwh {
+
+// ------------------------------------------------------------------------------------------------
+// K1: one lane = one hypothesis.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void swap_if(bool c, double& a, double& b) {
+    const double t = a;
+    a = c ? b : a;
+    b = c ? t : b;
+}
+
+__global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int m,
+                                                  const int32_t* __restrict__ idx, int k,
+                                                  float* __restrict__ hout, uint8_t* __restrict__ flags) {
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= k) return;
+    int id[4];
+    bool bad_index = false;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        id[i] = idx[4 * t + i];
+        if (id[i] < 0 || id[i] >= m) { bad_index = true; id[i] = 0; }
+    }
+    const bool repeated = (id[0] == id[1]) | (id[0] == id[2]) | (id[0] == id[3]) | (id[1] == id[2]) |
+                          (id[1] == id[3]) | (id[2] == id[3]);
+
+    // rows i = 0..3 of the shared elimination:  [ -x -y -1 | x*x' y*x' -x' | x*y' y*y' -y' ]
+    // i.e.  P h(1..3) + Q (h7,h8) = rhs  for the even DLT rows (cols 3..5) and the odd ones (6..8)
+    double M[4][9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float x = pa[2 * id[i]], y = pa[2 * id[i] + 1];
+        const float xp = pb[2 * id[i]], yp = pb[2 * id[i] + 1];
+        M[i][0] = -(double)x;  M[i][1] = -(double)y;  M[i][2] = -1.0;
+        M[i][3] = (double)(x * xp);  M[i][4] = (double)(y * xp);  M[i][5] = -(double)xp;  // float32 products
+        M[i][6] = (double)(x * yp);  M[i][7] = (double)(y * yp);  M[i][8] = -(double)yp;
+    }
+
+    // eliminate the shared 4x3 block with partial pivoting (first maximum wins)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int p = c;
+        double best = fabs(M[c][c]);
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) {
+            const double v = fabs(M[i][c]);
+            if (v > best) { best = v; p = i; }
+        }
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) {
+            const bool sw = (p == i);
+#pragma unroll
+            for (int j = c; j < 9; ++j) swap_if(sw, M[c][j], M[i][j]);
+        }
+        const double piv = M[c][c];
+#pragma unroll
+        for (int i = c + 1; i < 4; ++i) {
+            const double f = M[i][c] / piv;
+#pragma unroll
+            for (int j = c + 1; j < 9; ++j) M[i][j] = M[i][j] - f * M[c][j];
+        }
+    }
+    // row 3 is now  e1*h7 + e2*h8 = e3  and  o1*h7 + o2*h8 = o3
+    double a11 = M[3][3], a12 = M[3][4], b1 = M[3][5];
+    double a21 = M[3][6], a22 = M[3][7], b2 = M[3][8];
+    const bool sw2 = fabs(a21) > fabs(a11);
+    swap_if(sw2, a11, a21); swap_if(sw2, a12, a22); swap_if(sw2, b1, b2);
+    const double f2 = a21 / a11;
+    const double d2 = a22 - f2 * a12;
+    const double h8 = (b2 - f2 * b1) / d2;
+    const double h7 = (b1 - a12 * h8) / a11;
+
+    double h[9];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) {  // blk 0: h1..h3 from cols 3..5, blk 1: h4..h6 from cols 6..8
+        const int q = 3 + 3 * blk;
+        const double t2 = M[2][q + 2] - M[2][q] * h7 - M[2][q + 1] * h8;
+        const double r2 = t2 / M[2][2];
+        const double t1 = M[1][q + 2] - M[1][q] * h7 - M[1][q + 1] * h8 - M[1][2] * r2;
+        const double r1 = t1 / M[1][1];
+        const double t0 = M[0][q + 2] - M[0][q] * h7 - M[0][q + 1] * h8 - M[0][1] * r1 - M[0][2] * r2;
+        const double r0 = t0 / M[0][0];
+        h[3 * blk] = r0; h[3 * blk + 1] = r1; h[3 * blk + 2] = r2;
+    }
+    h[6] = h7; h[7] = h8; h[8] = 1.0;
+
+    double ss = 0.0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) ss = ss + h[i] * h[i];
+    const double nrm = sqrt(ss);
+    float n[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) n[i] = (float)(h[i] / nrm);
+    bool finite = true;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const float v = n[i] / n[8];
+        finite &= (fabsf(v) <= 3.4028234664e38f);  // false for NaN / inf
+        hout[9 * t + i] = v;
+    }
+    flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2: one wavefront = one hypothesis, lanes stride over correspondences, ballot + popcount.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void proj(const float (&h)[9], float x, float y, float& px, float& py, float& pw) {
+    float a0 = h[0] * x; a0 = fmaf(h[1], y, a0); a0 = a0 + h[2];
+    float a1 = h[3] * x; a1 = fmaf(h[4], y, a1); a1 = a1 + h[5];
+    float a2 = h[6] * x; a2 = fmaf(h[7], y, a2); a2 = a2 + h[8];
+    const float den = a2 + 1e-10f;
+    px = __fdiv_rn(a0, den); py = __fdiv_rn(a1, den); pw = __fdiv_rn(a2, den);
+}
+
+__device__ __forceinline__ float proj_err(const float (&h)[9], float x, float y, float xp, float yp) {
+    float px, py, pw;
+    proj(h, x, y, px, py, pw);
+    const float dx = px - xp, dy = py - yp;
+    const float s = dx * dx + dy * dy;
+    return __fsqrt_rn(s);
+}
+
+// float64 inverse of a float32 3x3 rounded back to float32 (numpy.linalg.inv on a float32 array,
+// ransac.py:74).  Plain LU with partial pivoting and reciprocal scaling; agrees with LAPACK's
+// result after the float32 rounding (checked on the golden hypotheses).
+__device__ __forceinline__ void inverse3(const float (&hf)[9], float (&inv)[9]) {
+    double A[3][3], B[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { A[i][j] = (double)hf[3 * i + j]; B[i][j] = (i == j) ? 1.0 : 0.0; }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        int p = c;
+        double best = fabs(A[c][c]);
+#pragma unroll
+        for (int i = c + 1; i < 3; ++i) {
+            const double v = fabs(A[i][c]);
+            if (v > best) { best = v; p = i; }
+        }
+#pragma unroll
+        for (int i = c + 1; i < 3; ++i) {
+            const bool sw = (p == i);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { swap_if(sw, A[c][j], A[i][j]); swap_if(sw, B[c][j], B[i][j]); }
+        }
+        const double r = 1.0 / A[c][c];
+#pragma unroll
+        for (int i = c + 1; i < 3; ++i) {
+            A[i][c] = A[i][c] * r;
+#pragma unroll
+            for (int j = c + 1; j < 3; ++j) A[i][j] = A[i][j] - A[i][c] * A[c][j];
+        }
+    }
+#pragma unroll
+    for (int col = 0; col < 3; ++col) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < i; ++q) B[i][col] = B[i][col] - A[i][q] * B[q][col];
+#pragma unroll
+        for (int i = 2; i >= 0; --i) {
+#pragma unroll
+            for (int q = i + 1; q < 3; ++q) B[i][col] = B[i][col] - A[i][q] * B[q][col];
+            B[i][col] = B[i][col] * (1.0 / A[i][i]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) inv[3 * i + j] = (float)B[i][j];
+}
+
+template <int LOSS>
+__global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs, const float* __restrict__ pa,
+                                                    const float* __restrict__ pb, int m, int k, double th, int need,
+                                                    long long hyp_base, int32_t* __restrict__ counts,
+                                                    uint64_t* __restrict__ masks, unsigned long long* best,
+                                                    float* __restrict__ errs) {
+    const int lane = threadIdx.x & 63;
+    const int hyp = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (hyp >= k) return;
+    float h[9], hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = hs[9 * (size_t)hyp + i];
+    if constexpr (LOSS != RWH_LOSS_FWD) inverse3(h, hi);
+
+    const int words = (m + 63) >> 6;
+    int count = 0;
+    for (int w = 0; w < words; ++w) {
+        const int j = w * 64 + lane;
+        bool inl = false;
+        if (j < m) {
+            const float2 a = reinterpret_cast<const float2*>(pa)[j];
+            const float2 b = reinterpret_cast<const float2*>(pb)[j];
+            float e;
+            if constexpr (LOSS == RWH_LOSS_FWD) e = proj_err(h, a.x, a.y, b.x, b.y);
+            else if constexpr (LOSS == RWH_LOSS_BACKWARD) e = proj_err(hi, b.x, b.y, a.x, a.y);
+            else { e = proj_err(h, a.x, a.y, b.x, b.y); e = e + proj_err(hi, b.x, b.y, a.x, a.y); }
+            inl = (double)e < th;
+            if (errs) errs[(size_t)hyp * m + j] = e;
+        }
+        const unsigned long long bal = __ballot(inl);
+        count += __popcll(bal);
+        if (masks && lane == 0) masks[(size_t)hyp * words + w] = bal;
+    }
+    if (lane == 0) {
+        counts[hyp] = count;
+        const unsigned long long gidx = (unsigned long long)(hyp_base + hyp);
+        const unsigned long long inv_idx = 0xFFFFFFFFull - gidx;
+        const unsigned long long key = ((unsigned long long)(unsigned)count << 32) | inv_idx;
+        // most waves lose against the running best: peek before paying for the atomic
+        if (key > __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[0], key);
+        if (count >= need && inv_idx > __hip_atomic_load(&best[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+            atomicMax(&best[1], inv_idx);
+    }
+}
+
+__global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ hs, const float* __restrict__ pts, int m,
+                                                      int inverse, float* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    float h[9], hi[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = hs[i];
+    if (inverse) {
+        inverse3(h, hi);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) h[i] = hi[i];
+    }
+    if (j >= m) return;
+    float px, py, pw;
+    proj(h, pts[2 * j], pts[2 * j + 1], px, py, pw);
+    out[j] = px; out[m + j] = py; out[2 * (size_t)m + j] = pw;
+}
+
+}  // namespace rwh
+
+extern "C" int rwh_project_points(const float* d_h, const float* d_pts, int m, int inverse, float* d_out, void* stream) {
+    using namespace rwh;
+    if (!d_h || !d_pts || !d_out || m <= 0) return RWH_E_INVALID;
+    hipLaunchKernelGGL(project_kernel, dim3((m + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), d_h, d_pts,
+                       m, inverse, d_out);
+    return check_launch();
+}
+
+extern "C" int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k,
+                                float* d_h, uint8_t* d_flags, void* stream) {
+    using namespace rwh;
+    if (!d_pts_a || !d_pts_b || !d_idx || !d_h || !d_flags || m <= 0 || k < 0) return RWH_E_INVALID;
+    if (k == 0) return RWH_OK;
+    hipLaunchKernelGGL(dlt4_kernel, dim3((k + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), d_pts_a, d_pts_b,
+                       m, d_idx, k, d_h, d_flags);
+    return check_launch();
+}
+
+extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k, double th,
+                               int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,
+                               uint64_t* d_best, float* d_err, void* stream) {
+    using namespace rwh;
+    if (!d_h || !d_pts_a || !d_pts_b || !d_counts || !d_best || m <= 0 || k < 0 || hyp_base < 0) return RWH_E_INVALID;
+    if (hyp_base + k > 0xFFFFFFFFll) return RWH_E_INVALID;
+    if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ) return RWH_E_INVALID;
+    if (k == 0) return RWH_OK;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const dim3 grid((k + 3) / 4), block(256);
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(d_best);
+    if (loss == RWH_LOSS_FWD)
+        hipLaunchKernelGGL(score_kernel<RWH_LOSS_FWD>, grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, th, need,
+                           (long long)hyp_base, d_counts, d_masks, best, d_err);
+    else if (loss == RWH_LOSS_BACKWARD)
+        hipLaunchKernelGGL(score_kernel<RWH_LOSS_BACKWARD>, grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, th, need,
+                           (long long)hyp_base, d_counts, d_masks, best, d_err);
+    else
+        hipLaunchKernelGGL(score_kernel<RWH_LOSS_REPROJ>, grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, th, need,
+                           (long long)hyp_base, d_counts, d_masks, best, d_err);
+    return check_launch();
+}

@@ -1,0 +1,360 @@
+"""MI355X-backed mirror of the reference's `homography.py` call surface.
+
+Same names, argument meaning, defaults, return types and error behaviour as
+choice17/ransac_with_homography `homography.py`; the per-pixel work (grid ->
+inverse homography -> divide -> mask -> gather -> lerp, homography.py:108-209)
+runs in the hand-written HIP kernel K3 behind `rwh_warp_backward` (include/rwh.h).
+
+numpy arrays in -> numpy arrays out (uploaded / downloaded around the kernel);
+torch-ROCm tensors in -> torch-ROCm tensors out (no host round trip: bilinear
+results are float32 instead of the reference's float64, nn keeps the dtype).
+
+What stays on the host, as in SURVEY.md 8(a) row a3: the O(1) 3x3 / 8x8 solves
+(`calcHomographyLinear`, `inv(H)`, output bounding box) in numpy, exactly the
+reference's arithmetic.  There is no CPU implementation of the warp here: without
+librwh_hip.so and a GPU the warps raise `RwhUnavailable`.
+
+Documented divergences from the reference:
+  * the +1 bilinear tap is clamped where the reference raises IndexError
+    (coordinate exactly on the last column/row; its weight is 0 there);
+  * scan-mode bounds larger than the source are clipped to the source (the
+    reference raises IndexError or reads wrapped rows);
+  * the bilinear blend is float32 on float64-derived weights (<= 1e-4 relative to
+    the reference's float64 blend, typically 3e-7); uint8 results can therefore
+    differ by 1 LSB where the float64 value sits within ~1e-5 of an integer;
+  * `cylindericlMap` / `cylindricalWarp` / `cylindericalTransform` (dead code in
+    the reference, needs OpenCV) are not provided beyond an import-compatible stub.
+"""
+import numpy as np
+
+from . import _lib, kernels
+
+__all__ = [
+    "calc_corresp", "calc_correspLinear", "calc_correspCollective", "calc_correspLinearCollective",
+    "calcHomography", "calcHomographyLinear", "calcH", "nearestNeighbor", "bilinear", "convertfunc",
+    "wrapPerspective", "wrapPerspectiveScan", "perspectiveTransform", "transformImage", "transformImageH",
+    "BLENDDIR", "addAlpha", "stitchPanorama", "cylindericlMap",
+]
+
+
+# ------------------------------------------------------------------ design matrices (host, O(N)) ----
+def _pair_rows(u, v, sign):
+    """Shared builder.  sign=-1: DLT rows [-x,-y,-1,0,0,0, x*x', y*x', x'] (homography.py:4-14, 30-46);
+    sign=+1: linear rows [x,y,1,0,0,0,-x*x',-y*x'] with b = (x', y') (homography.py:16-28, 48-69).
+    Products are formed in the input dtype, storage is float32, as in the reference."""
+    u = np.asarray(u)
+    v = np.asarray(v)
+    n = u.shape[0]
+    x, y, xp, yp = u[:, 0], u[:, 1], v[:, 0], v[:, 1]
+    if sign < 0:
+        a = np.zeros((n, 18), dtype=np.float32)
+        a[:, 0] = -x; a[:, 1] = -y; a[:, 2] = -1
+        a[:, 6] = x * xp; a[:, 7] = y * xp; a[:, 8] = xp
+        a[:, 12] = -x; a[:, 13] = -y; a[:, 14] = -1
+        a[:, 15] = x * yp; a[:, 16] = y * yp; a[:, 17] = yp
+        return a.reshape(2 * n, 9)
+    a = np.zeros((n, 16), dtype=np.float32)
+    b = np.zeros((n, 2), dtype=np.float32)
+    a[:, 0] = x; a[:, 1] = y; a[:, 2] = 1
+    a[:, 6] = -x * xp; a[:, 7] = -y * xp
+    a[:, 11] = x; a[:, 12] = y; a[:, 13] = 1
+    a[:, 14] = -x * yp; a[:, 15] = -y * yp
+    b[:, 0] = xp; b[:, 1] = yp
+    return a.reshape(2 * n, 8), b.reshape(2 * n, 1)
+
+
+def calc_corresp(u, v):
+    """8 x 9 DLT matrix of 4 pairs, float32 (homography.py:4-14)."""
+    return _pair_rows(np.asarray(u)[:4], np.asarray(v)[:4], -1)
+
+
+def calc_correspLinear(u, v):
+    """(8 x 8 A, 8 x 1 b), float32 (homography.py:16-28)."""
+    return _pair_rows(np.asarray(u)[:4], np.asarray(v)[:4], +1)
+
+
+def calc_correspCollective(u, v):
+    """2N x 9 DLT matrix (homography.py:30-46)."""
+    return _pair_rows(u, v, -1)
+
+
+def calc_correspLinearCollective(u, v):
+    """(2N x 8 A, 2N x 1 b) (homography.py:48-69)."""
+    return _pair_rows(u, v, +1)
+
+
+# ------------------------------------------------------------------------------------- solvers ----
+def calcHomography(u, v, collective=False):
+    """DLT homography, float32 3x3 with h33 == 1 (homography.py:71-88).
+
+    4 float32 pairs (the RANSAC sampling case) run through the batched GPU
+    generator K1 with a single hypothesis.  The N-point form and float64 inputs
+    (never used by the reference's live code) take the host SVD, which is the
+    reference's own arithmetic."""
+    u = np.asarray(u)
+    v = np.asarray(v)
+    if not collective and u.dtype == np.float32 and v.dtype == np.float32 and u.shape[0] == 4:
+        import torch
+        dev = _lib.require_gpu()
+        pa = torch.from_numpy(np.ascontiguousarray(u[:, :2])).to(dev)
+        pb = torch.from_numpy(np.ascontiguousarray(v[:, :2])).to(dev)
+        idx = torch.arange(4, dtype=torch.int32, device=dev).reshape(1, 4)
+        H, _ = kernels.dlt4_batched(pa, pb, idx)
+        return H.cpu().numpy().reshape(3, 3)
+    mat = calc_correspCollective(u, v) if collective else calc_corresp(u, v)
+    _, _, vt = np.linalg.svd(mat)
+    h = vt[-1].reshape(3, 3)
+    return h / h.item(8)
+
+
+def calcHomographyLinear(u, v, collective=False):
+    """Normal-equation homography with h33 == 1, float64 3x3 (homography.py:90-105).
+    O(1) host work (called once per scanner apply / RANSAC run)."""
+    A, b = calc_correspLinearCollective(u, v) if collective else calc_correspLinear(u, v)
+    h = np.linalg.inv(A.T @ A) @ (A.T @ b)
+    return np.array([[h.item(0), h.item(1), h.item(2)],
+                     [h.item(3), h.item(4), h.item(5)],
+                     [h.item(6), h.item(7), 1]])
+
+
+calcH = calcHomographyLinear  # name used by BASELINE.json's north_star
+
+
+# ------------------------------------------------------------------------------- warp plumbing ----
+def _is_tensor(x):
+    return type(x).__module__.startswith("torch")
+
+
+def _blank_origin(img):
+    """Mirror homography.py:112-116 / 126-130 on the caller's HOST array (the kernel does the
+    same to the device copy): channels 0..2, and 3 when there are exactly 4."""
+    img[0, 0, 0] = 0
+    img[0, 0, 1] = 0
+    img[0, 0, 2] = 0
+    if img.shape[2] == 4:
+        img[0, 0, 3] = 0
+
+
+def _to_device(img):
+    """-> (GPU tensor [H,W,C] uint8|float32, was_numpy, result dtype for nn)."""
+    import torch
+    dev = _lib.require_gpu()
+    if _is_tensor(img):
+        t = img
+        if not t.is_cuda:
+            t = t.to(dev)
+        if t.dtype not in (torch.uint8, torch.float32):
+            t = t.to(torch.float32)
+        return t.contiguous(), False, None
+    a = np.asarray(img)
+    if a.ndim != 3:
+        raise ValueError("not enough values to unpack (expected 3, got %d)" % a.ndim)  # img.shape unpack
+    if a.shape[2] not in (3, 4):
+        raise IndexError("index out of bounds: the warp supports 3 or 4 channels")
+    src = a if a.dtype in (np.uint8, np.float32) else a.astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(src)).to(dev), True, a.dtype
+
+
+def _warp(img, H, grid, bound_hw, convert, u8_out):
+    """Common body of wrapPerspective / wrapPerspectiveScan from `invH = inv(H)` on."""
+    import torch
+    if convert not in kernels.INTERP:
+        raise KeyError(convert)  # convertfunc[convert], homography.py:179 / 208
+    inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))  # homography.py:172 / 203 (raises LinAlgError)
+    src, was_numpy, np_dtype = _to_device(img)
+    if convert == "nn":
+        out_dtype = src.dtype
+    else:
+        out_dtype = torch.uint8 if u8_out else torch.float32
+    out = kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=True)
+    if not was_numpy:
+        return out
+    _blank_origin(img)
+    res = out.cpu().numpy()
+    if convert == "nn":
+        return res if res.dtype == np_dtype else res.astype(np_dtype)
+    return res if u8_out else res.astype(np.float64)  # the reference's bilinear yields float64
+
+
+def _bounds(h, w, H, boundary):
+    """Output bounding box, homography.py:143-163 (host numpy, 4 points)."""
+    bnd = np.array([[0, w - 1, w - 1, 0],
+                    [0, 0, h - 1, h - 1],
+                    [1., 1, 1, 1]])
+    bnd_n = np.asarray(H) @ bnd
+    bnd_n /= bnd_n[-1, :]
+    max_x = int(np.max(bnd_n[0, :])); min_x = int(np.min(bnd_n[0, :]))
+    max_y = int(np.max(bnd_n[1, :])); min_y = int(np.min(bnd_n[1, :]))
+    if boundary:
+        min_x = max(min_x, 0)
+        min_y = max(min_y, 0)
+    return min_x, min_y, max_x - min_x + 1, max_y - min_y + 1
+
+
+def _wrap_perspective(img, H, convert, boundary, u8_out):
+    h, w, _ = img.shape
+    min_x, min_y, max_w, max_h = _bounds(h, w, H, boundary)
+    if max_w <= 0 or max_h <= 0:
+        raise ValueError("Number of samples, %d, must be non-negative." % min(max_w, max_h))  # np.linspace
+    grid = kernels.Grid(min_x, min_x + max_w - 1, max_w, min_y, min_y + max_h - 1, max_h)
+    return _warp(img, H, grid, (h, w), convert, u8_out), min_x, min_y
+
+
+def wrapPerspective(img, H, convert='nn', boundary=0, crop=True):
+    """Auto-bounds backward warp (homography.py:142-184).  Returns (img_n, min_x, min_y);
+    img_n is float64 for 'bilinear' and keeps the image dtype for 'nn'."""
+    if not crop:
+        raise NotImplementedError("crop=False is dead, shape-inconsistent code in the reference (homography.py:180-183)")
+    return _wrap_perspective(img, H, convert, boundary, False)
+
+
+def wrapPerspectiveScan(img, H, res, convert='nn'):
+    """Fixed-resolution backward warp (homography.py:186-209): grid linspace(0,w,w) x
+    linspace(0,h,h); the bounds test uses `res` (clipped to the source here)."""
+    h, w = res
+    grid = kernels.Grid(0, w, w, 0, h, h)
+    return _warp(img, H, grid, (h, w), convert, False), 0, 0
+
+
+perspectiveTransform = wrapPerspective  # name used by BASELINE.json's north_star
+
+
+def nearestNeighbor(z_t, img, h, w, mh, mw):
+    """Interpolator entry of `convertfunc` (homography.py:108-121) is fused into the warp
+    kernel; it cannot be fed precomputed coordinates."""
+    raise NotImplementedError("fused into rwh_warp_backward: call wrapPerspective(..., convert='nn')")
+
+
+def bilinear(z_t, img, h, w, mh, mw):
+    """See nearestNeighbor (homography.py:123-138)."""
+    raise NotImplementedError("fused into rwh_warp_backward: call wrapPerspective(..., convert='bilinear')")
+
+
+convertfunc = {'nn': nearestNeighbor, 'bilinear': bilinear}
+
+
+def transformImage(img, u, v, box=None, method='bilinear'):
+    """Homography from 4 corner pairs + warp + uint8 + crop (homography.py:211-228).
+    u, v: 3 x 4 homogeneous corners; `box=(h,w)` selects the scanner's fixed-resolution mode.
+    The uint8 truncation is fused into the kernel (dst_dtype U8)."""
+    u = np.asarray(u)
+    v = np.asarray(v)
+    H = calcHomographyLinear(u.T[:, :2], v.T[:, :2])
+    if box is None:
+        imgn, mx, my = _wrap_perspective(img, H, method, 0, True)
+    else:
+        h, w = box
+        imgn = _warp(img, H, kernels.Grid(0, w, w, 0, h, h), (h, w), method, True)
+        mx = my = 0
+    if not _is_tensor(imgn) and imgn.dtype != np.uint8:
+        imgn = imgn.astype(np.uint8)
+    sx = int(v[0, 0] - mx); sy = int(v[1, 0] - my)
+    ex = int(v[0, 2] - mx); ey = int(v[1, 2] - my)
+    return imgn[sy:ey + 1, sx:ex + 1, :]
+
+
+def transformImageH(img, H, method='bilinear'):
+    """Warp by a given H (homography.py:230-242): uint8 for 3-channel results, 4-channel
+    results stay floating point.  Returns (img, mx, my)."""
+    if img.shape[2] == 3:
+        imgn, mx, my = _wrap_perspective(img, H, method, 0, True)
+        if not _is_tensor(imgn) and imgn.dtype != np.uint8:
+            imgn = imgn.astype(np.uint8)
+        return imgn, mx, my
+    return _wrap_perspective(img, H, method, 0, False)
+
+
+# ------------------------------------------------------------------------- alpha + compositor ----
+class BLENDDIR(object):
+    LEFT = 0
+    RIGHT = 1
+    TOP = 2
+    DOWN = 3
+
+
+def addAlpha(img, method="Rate", rate=0.2, direction=BLENDDIR.LEFT, alphaOnly=False):
+    """Append (or return) an alpha plane, float32 (homography.py:250-286).  'Rate' is the only
+    mode the reference finishes; its 'Gradient' branch (half-implemented, prints
+    'not implement yet') is reproduced for the LEFT/RIGHT ramps it defines."""
+    h, w, c = img.shape
+    rate += 1e-10
+
+    def ramp():
+        if direction == BLENDDIR.RIGHT and alphaOnly:
+            x = np.linspace(w - 1, 0, w); y = np.linspace(h - 1, 0, h)
+        elif direction == BLENDDIR.LEFT:
+            x = np.linspace(0, w - 1, w); y = np.linspace(0, h - 1, h)
+        else:
+            raise UnboundLocalError("local variable 'br' referenced before assignment")
+        xx, yy = np.meshgrid(x, y)
+        return (xx + yy) / (w + h) * 0.5
+
+    if not alphaOnly:
+        imgn = np.zeros((h, w, c + 1), dtype=np.float32)
+        imgn[:, :, :c] = img
+        if method == 'Rate':
+            print(rate)
+            imgn[:, :, c] = rate
+        elif method == 'Gradient':
+            imgn[:, :, c] = ramp()
+            print('not implement yet')
+        return imgn
+    alpha = np.zeros((h, w, 1), dtype=np.float32)
+    if method == 'Rate':
+        print(rate)
+        alpha[:, :, 0] = rate
+    elif method == 'Gradient':
+        alpha[:, :, 0] = ramp()
+        print('not implement yet')
+    return alpha
+
+
+def _stitch_geometry(wt, ht, wq, hq, mx, my):
+    """Paste rectangles and canvas size, homography.py:303-321."""
+    tsx = 0; tsy = 0; tex = wt - 1; tey = ht - 1
+    qsx = 0; qsy = 0; qex = wq - 1; qey = hq - 1
+    if mx < 0 and my < 0:
+        qsx = -mx; qsy = -my; qex = -mx + wq - 1; qey = -my + hq - 1
+    elif mx < 0:
+        tsy = my; tey = my + ht - 1
+        qsx = -mx; qex = -mx + wq - 1
+    elif my < 0:
+        tsx = mx; tex = mx + wt - 1
+        qsy = -my; qey = -my + hq - 1
+    else:
+        tsx = mx; tsy = my; tex = mx + wt - 1; tey = my + ht - 1
+    return (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (max(tex + 1, qex + 1), max(tey + 1, qey + 1))
+
+
+def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0.2):
+    """Warp imgT by H on the GPU and composite it with imgQ (homography.py:288-338).
+    `method` is ignored exactly as in the reference (always bilinear).  The compositor is
+    elementwise host numpy for now (SURVEY.md 8f row f-1 lists its fusion as a next step)."""
+    if blending:
+        imgT = addAlpha(imgT, method=blending, rate=blendrate)
+    img_t, mx, my = transformImageH(imgT, H)
+    ht, wt, ct = img_t.shape
+    hq, wq, cq = imgQ.shape
+    (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (fw, fh) = _stitch_geometry(wt, ht, wq, hq, mx, my)
+    if blending:
+        imgn = np.zeros((fh, fw, ct), dtype=np.float32)
+        imgn[qsy:qey + 1, qsx:qex + 1, :3] = imgQ[:, :, :3].astype(np.float32)
+        imgn[:, :, 3] += 1e-10
+        if blending == 'Rate':
+            imgn[qsy:qey + 1, qsx:qex + 1, 3] = 1 + 1e-10 - blendrate
+        else:
+            imgn[qsy:qey + 1, qsx:qex + 1, 3] = 1
+        win = imgn[tsy:tey + 1, tsx:tex + 1]
+        base = win[:, :, 3:4] + img_t[:, :, 3:4]
+        imgn[tsy:tey + 1, tsx:tex + 1, :3] = (win[:, :, 3:4] / base) * win[:, :, :3] + (img_t[:, :, 3:4] / base) * img_t[:, :, :3]
+        return imgn[:, :, :3].astype(np.uint8)
+    imgn = np.zeros((fh, fw, ct), dtype=np.uint8)
+    imgn[tsy:tey + 1, tsx:tex + 1, :] = img_t
+    imgn[qsy:qey + 1, qsx:qex + 1, :] = imgQ
+    return imgn
+
+
+def cylindericlMap(img, f=1600):
+    """Import-compatibility stub: ransac.py:3 imports this name but no live code calls it
+    (its only call sites are commented out, ransac.py:249-251).  Needs cv2.remap."""
+    raise NotImplementedError("cylindrical warps are dead code in the reference and out of scope (SURVEY.md C11)")

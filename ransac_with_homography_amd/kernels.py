@@ -1,0 +1,139 @@
+"""Tensor-level wrappers over the C ABI (include/rwh.h): torch-ROCm tensors in,
+torch-ROCm tensors out, work enqueued on torch's current HIP stream.
+
+torch is plumbing here (device memory, streams); every computation below happens
+inside librwh_hip.so.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (RWH_BILINEAR, RWH_F32, RWH_LOSS, RWH_NEAREST, RWH_U8, RWH_WARP_ZERO_ORIGIN, check)
+
+_DTYPE = {torch.uint8: RWH_U8, torch.float32: RWH_F32}
+INTERP = {"nn": RWH_NEAREST, "bilinear": RWH_BILINEAR}
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _dev_check(*tensors):
+    for t in tensors:
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.is_contiguous()):
+            raise ValueError("expected contiguous tensors on the GPU")
+
+
+class Grid:
+    """Output sampling grid with numpy.linspace semantics on both axes
+    (reference homography.py:166-167 and 197-198)."""
+
+    __slots__ = ("x0", "step_x", "x_last", "out_w", "y0", "step_y", "y_last", "out_h")
+
+    def __init__(self, x_start, x_stop, out_w, y_start, y_stop, out_h):
+        self.out_w, self.out_h = int(out_w), int(out_h)
+        self.x0, self.x_last = float(x_start), float(x_stop)
+        self.y0, self.y_last = float(y_start), float(y_stop)
+        # numpy.linspace: step = (stop - start) / (num - 1)
+        self.step_x = (self.x_last - self.x0) / (self.out_w - 1) if self.out_w > 1 else 0.0
+        self.step_y = (self.y_last - self.y0) / (self.out_h - 1) if self.out_h > 1 else 0.0
+        if self.out_w == 1:
+            self.x_last = self.x0
+        if self.out_h == 1:
+            self.y_last = self.y0
+
+
+def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=True, rows=None, out=None):
+    """Launch K3.  `src`: [B,H,W,C] or [H,W,C] uint8/float32 GPU tensor.
+    Returns a tensor [B,rows,out_w,C] (or without B) of `out_dtype` holding
+    output rows `rows=(begin,end)` (default: all)."""
+    lib = _lib.load()
+    _dev_check(src)
+    squeeze = src.dim() == 3
+    if squeeze:
+        src = src.unsqueeze(0)
+    B, H, W, C = src.shape
+    if src.dtype not in _DTYPE or out_dtype not in _DTYPE:
+        raise ValueError("unsupported image dtype")
+    r0, r1 = (0, grid.out_h) if rows is None else rows
+    if out is None:
+        out = torch.empty((B, r1 - r0, grid.out_w, C), dtype=out_dtype, device=src.device)
+    else:
+        _dev_check(out)
+        assert out.dtype == out_dtype and out.numel() == B * (r1 - r0) * grid.out_w * C
+    ih = np.ascontiguousarray(inv_h, dtype=np.float64).reshape(9)
+    st = lib.rwh_warp_backward(
+        _ptr(src), H, W, C, _DTYPE[src.dtype], src.stride(0) * src.element_size(), B,
+        ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1,
+        grid.x0, grid.step_x, grid.x_last, grid.y0, grid.step_y, grid.y_last,
+        grid.out_h, grid.out_w, int(bound_hw[0]), int(bound_hw[1]), INTERP[interp],
+        _ptr(out), _DTYPE[out_dtype], (r1 - r0) * grid.out_w * C * out.element_size(),
+        r0, r1, RWH_WARP_ZERO_ORIGIN if zero_origin else 0, _lib.stream_ptr())
+    check(st, "rwh_warp_backward")
+    return out[0] if squeeze else out
+
+
+def dlt4_batched(pts_a, pts_b, idx):
+    """Launch K1.  pts_*: [M,2] float32, idx: [K,4] int32 -> (H [K,9] float32, flags [K] uint8)."""
+    lib = _lib.load()
+    _dev_check(pts_a, pts_b, idx)
+    assert pts_a.dtype == torch.float32 and pts_b.dtype == torch.float32 and idx.dtype == torch.int32
+    M, K = pts_a.shape[0], idx.shape[0]
+    assert pts_a.shape == (M, 2) and pts_b.shape == (M, 2) and idx.shape == (K, 4)
+    H = torch.empty((K, 9), dtype=torch.float32, device=idx.device)
+    flags = torch.empty((K,), dtype=torch.uint8, device=idx.device)
+    check(lib.rwh_dlt4_batched(_ptr(pts_a), _ptr(pts_b), M, _ptr(idx), K, _ptr(H), _ptr(flags), _lib.stream_ptr()),
+          "rwh_dlt4_batched")
+    return H, flags
+
+
+def new_best(device):
+    """Zeroed accumulator for rwh_score_count's packed argmax keys (2 x int64)."""
+    return torch.zeros(2, dtype=torch.int64, device=device)
+
+
+def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=True, want_err=False):
+    """Launch K2.  Returns (counts [K] int32, masks [K,ceil(M/64)] int64 or None, err [K,M] float32 or None);
+    `best` (from new_best) is updated in place with atomic max."""
+    lib = _lib.load()
+    _dev_check(H, pts_a, pts_b, best)
+    K, M = H.shape[0], pts_a.shape[0]
+    words = (M + 63) // 64
+    counts = torch.empty((K,), dtype=torch.int32, device=H.device)
+    masks = torch.empty((K, words), dtype=torch.int64, device=H.device) if want_masks else None
+    err = torch.empty((K, M), dtype=torch.float32, device=H.device) if want_err else None
+    check(lib.rwh_score_count(_ptr(H), _ptr(pts_a), _ptr(pts_b), M, K, float(th), RWH_LOSS[loss], int(need),
+                              int(hyp_base), _ptr(counts), _ptr(masks) if want_masks else None, _ptr(best),
+                              _ptr(err) if want_err else None, _lib.stream_ptr()), "rwh_score_count")
+    return counts, masks, err
+
+
+def project_points(h9, pts, inverse):
+    """Launch the projection kernel: h9 [9] float32, pts [M,2] float32 -> [3,M] float32."""
+    lib = _lib.load()
+    _dev_check(h9, pts)
+    M = pts.shape[0]
+    out = torch.empty((3, M), dtype=torch.float32, device=pts.device)
+    check(lib.rwh_project_points(_ptr(h9), _ptr(pts), M, 1 if inverse else 0, _ptr(out), _lib.stream_ptr()),
+          "rwh_project_points")
+    return out
+
+
+def decode_best(best_words, k_total):
+    """Unpack the two argmax words (host ints) -> (winner_index, count, early_exit).
+    Word 1 (first index reaching `need`) takes precedence, like the reference's
+    `break` (ransac.py:186-190); otherwise word 0 = max count, lowest index."""
+    w0, w1 = int(best_words[0]), int(best_words[1])
+    if w1 != 0:
+        return 0xFFFFFFFF - w1, None, True
+    if (w0 >> 32) == 0:  # nothing ever scored > 0: the reference keeps no model (ransac.py:199)
+        return None, 0, False
+    return 0xFFFFFFFF - (w0 & 0xFFFFFFFF), w0 >> 32, False
+
+
+def need_count(m, d, n):
+    """ransac.py:169,186: count >= m*d/100 + n, as an integer threshold."""
+    return int(math.ceil(m * d / 100 + n))

@@ -1,0 +1,238 @@
+"""MI355X-backed mirror of the reference's `ransac.py` call surface.
+
+`HomoModel`, `RANSAC` and `stitching` keep the reference's names, constructor
+arguments, defaults, return values and data layout (features x observations,
+ransac.py:159-166).  The k-iteration Python loop of `RANSAC.run`
+(ransac.py:176-202) is replaced by three launches on the GPU:
+
+    K1  rwh_dlt4_batched   all k four-point DLT hypotheses        (ransac.py:178-180)
+    K2  rwh_score_count    k x M reprojection errors, `err < th`,  (ransac.py:182-184)
+                           wavefront ballot + popcount, and the
+                           order-independent form of the accept
+                           rules (packed argmax keys)             (ransac.py:186-202)
+
+followed by the reference's own final N-point refit on the host
+(ransac.py:206-211 -> calcHomographyLinear, O(1)).
+
+Sampling parity: the k x 4 index table is drawn from numpy's global legacy
+generator exactly as k successive `np.random.randint(0, M, 4)` calls would
+(ransac.py:177), and the generator is left where the reference would leave it
+(an early exit at iteration e consumes only e+1 draws).
+
+There is no CPU implementation of the loop here: without librwh_hip.so and a GPU
+`RANSAC.run` raises `RwhUnavailable`.
+"""
+import numpy as np
+
+from . import _lib, kernels
+from .homography import calcHomography, calcHomographyLinear, cylindericlMap, stitchPanorama  # noqa: F401
+
+LVL = 0
+
+
+def DEBUG(*args):
+    if LVL >= 1:
+        print("[DEBUG]", *args)
+
+
+def _weak_threshold(th):
+    """`err_total < self.th` (ransac.py:183) compares float32 errors with `th`:
+    Python scalars are weak (compared as float32), numpy float64 scalars promote
+    the comparison to float64.  Return the double the kernel must compare with."""
+    if type(th) in (int, float, bool) or isinstance(th, (np.float32, np.float16, np.integer)):
+        return float(np.float32(th))
+    return float(th)
+
+
+def _points_rows(P):
+    """features x observations (2 x M or 3 x M) -> contiguous M x 2 float32."""
+    P = np.asarray(P)
+    return np.ascontiguousarray(P.T[:, :2], dtype=np.float32)
+
+
+class Model(object):
+    __slots__ = ('val', 'th', 'd', 'n')
+
+    def fit(self, X, Y):
+        raise NotImplementedError
+
+    def fwd(self, X):
+        raise NotImplementedError
+
+    def dist(self, predY, trueY):
+        raise NotImplementedError
+
+
+class HomoModel(Model):
+    """ransac.py:22-98."""
+
+    def __init__(self, th=5, d=50, n=4):
+        self.th = th
+        self.d = d
+        self.n = n
+        self.val = np.empty((3, 3), dtype=np.float32)
+
+    def fit(self, X, Y, collective=False):
+        """ransac.py:30-53.  X, Y: 2 x n or 3 x n (n == self.n, or more with collective=True)."""
+        nx, mx = X.shape
+        ny, my = Y.shape
+        assert ((mx == my) and (mx == self.n)) or ((mx == my) and (mx > self.n) and collective), \
+            "invalid data size should be %d" % self.n
+        assert (nx == ny) and nx in [2, 3], "invalid input dimension for row numbers"
+        if collective:
+            self.val = calcHomographyLinear(X.T[:, :2], Y.T[:, :2], True)
+        else:
+            self.val = calcHomography(X.T[:, :2], Y.T[:, :2], False)
+        return self.val
+
+    # -- projection helpers: one launch of the projection kernel each -------------------------
+    def _project(self, P, inverse):
+        import torch
+        nrow, m = P.shape
+        assert nrow in [2, 3], "invalid input dimension for row numbers"
+        dev = _lib.require_gpu()
+        h9 = torch.from_numpy(np.ascontiguousarray(self.val, dtype=np.float32).reshape(9)).to(dev)
+        pts = torch.from_numpy(_points_rows(P)).to(dev)
+        return kernels.project_points(h9, pts, inverse).cpu().numpy()
+
+    def fwd(self, X):
+        """val @ [X;1] / (row2 + 1e-10), float32 3 x M (ransac.py:55-64)."""
+        return self._project(X, False)
+
+    def reproj(self, Y):
+        """inv(val) @ [Y;1] / (row2 + 1e-10) (ransac.py:66-76)."""
+        return self._project(Y, True)
+
+    def dist(self, predY, trueY):
+        """Column-wise L2 distance (ransac.py:78-82); two arrays in, one out: host numpy."""
+        delta = (predY - trueY)
+        delta = np.sum(delta * delta, axis=0)
+        return np.sqrt(delta)
+
+    def computeLoss(self, X, Y, method="reproj"):
+        """Per-correspondence loss, float32 [M] (ransac.py:84-98), from the scorer kernel."""
+        import torch
+        if method not in _lib.RWH_LOSS:
+            exit("Invalid method!")  # ransac.py:97
+        dev = _lib.require_gpu()
+        h9 = torch.from_numpy(np.ascontiguousarray(self.val, dtype=np.float32).reshape(1, 9)).to(dev)
+        pa = torch.from_numpy(_points_rows(X)).to(dev)
+        pb = torch.from_numpy(_points_rows(Y)).to(dev)
+        best = kernels.new_best(dev)
+        _, _, err = kernels.score_count(h9, pa, pb, 0.0, method, 1 << 30, best, want_masks=False, want_err=True)
+        return err[0].cpu().numpy()
+
+
+class RANSAC(object):
+    """ransac.py:137-213."""
+
+    __slots__ = ('model', 'th', 'd', 'n', 'k', 'last_run')
+
+    def __init__(self, model, k=1000):
+        self.model = model
+        self.th = model.th
+        self.d = model.d
+        self.n = model.n
+        self.k = k
+        self.last_run = None
+
+    def computeLoss(self, X, Y, method="reproj"):
+        return self.model.computeLoss(X, Y, method)
+
+    def run(self, data, method="reproj"):
+        """Returns (finalModel float64 3x3, (inlier_indices,), count) like ransac.py:159-213 and
+        sets `model.val`.  `self.last_run` keeps diagnostics (winner index, early-exit flag,
+        per-hypothesis flags/counts tensors) that the reference does not expose."""
+        import torch
+        X, Y = data
+        nx, mx = X.shape
+        ny, my = Y.shape
+        assert mx == my, "data observation not consistent!"
+        if method not in _lib.RWH_LOSS:
+            exit("Invalid method!")
+        if self.n != 4:
+            raise NotImplementedError("the homography model samples exactly 4 correspondences (ransac.py:270)")
+        dev = _lib.require_gpu()
+        need = mx * self.d / 100 + self.n
+        k = int(self.k)
+
+        # sampling: identical stream to k successive randint(0, mx, 4) calls (ransac.py:177)
+        rng_state = np.random.get_state()
+        idx_host = np.random.randint(0, mx, (k, self.n))
+
+        pa = torch.from_numpy(_points_rows(X)).to(dev)
+        pb = torch.from_numpy(_points_rows(Y)).to(dev)
+        idx = torch.from_numpy(idx_host.astype(np.int32)).to(dev)
+        best = kernels.new_best(dev)
+        Hs, flags = kernels.dlt4_batched(pa, pb, idx)
+        counts, masks, _ = kernels.score_count(Hs, pa, pb, _weak_threshold(self.th), method,
+                                               kernels.need_count(mx, self.d, self.n), best)
+        winner, _, early = kernels.decode_best(best.cpu().numpy(), k)
+
+        last_iter = winner if early else k - 1
+        if early:  # leave the generator where the reference's `break` would
+            np.random.set_state(rng_state)
+            np.random.randint(0, mx, (winner + 1, self.n))
+        tail = counts[[last_iter] + ([winner] if winner is not None else [])].cpu().numpy()
+        if tail[0] < need:  # ransac.py:203-204 (uses the LAST iteration's count in the test)
+            best_cnt = int(tail[1]) if winner is not None else 0
+            print("Warning:: fitting model does not exceed required threshold %d vs %d" % (best_cnt, need))
+
+        if winner is None or int(tail[1]) == 0:
+            # ransac.py:206-208 with inliers_pos_final = None: np.where(None) -> empty -> fit asserts
+            inliers = (np.array([], dtype=np.int64),)
+            totalfit = 0
+        else:
+            words = masks[winner].cpu().numpy().view(np.uint64)
+            bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:mx]
+            inliers = (np.nonzero(bits)[0].astype(np.int64),)
+            totalfit = np.int64(tail[1])
+        self.last_run = {"winner": winner, "early_exit": early, "counts": counts, "flags": flags,
+                         "hypotheses": Hs, "idx": idx_host}
+        inliers_x = X[:, inliers[0]]
+        inliers_y = Y[:, inliers[0]]
+        DEBUG("Fitting final model using all inliers")
+        finalModel = self.model.fit(inliers_x, inliers_y, collective=True)
+        self.model.val = finalModel
+        return finalModel, inliers, totalfit
+
+
+def _match_features(trainImg, queryImg):
+    """ORB + brute-force Hamming matcher of ransac.py:252-267.  This is OpenCV C++ and outside the
+    GPU path; it runs only when cv2 is installed."""
+    try:
+        import cv2
+    except ImportError as e:
+        raise ImportError("stitching() needs OpenCV for ORB/BFMatcher, or pass matches=(ptsA, ptsB) "
+                          "(float32 [N,2] each, the matchespoints.npy layout)") from e
+    trainImg_gray = cv2.cvtColor(trainImg, cv2.COLOR_RGB2GRAY)
+    queryImg_gray = cv2.cvtColor(queryImg, cv2.COLOR_RGB2GRAY)
+    descriptor = cv2.ORB_create()
+    kpsA, featuresA = descriptor.detectAndCompute(trainImg_gray, None)
+    kpsB, featuresB = descriptor.detectAndCompute(queryImg_gray, None)
+    bf = cv2.BFMatcher(cv2.NORM_HAMMING, crossCheck=True)
+    found = sorted(bf.match(featuresA, featuresB), key=lambda m: m.distance)
+    kpsA = np.float32([kp.pt for kp in kpsA])
+    kpsB = np.float32([kp.pt for kp in kpsB])
+    return np.float32([kpsA[m.queryIdx] for m in found]), np.float32([kpsB[m.trainIdx] for m in found])
+
+
+def stitching(trainImg, queryImg, ransacMet="fwd", th=5, d=70, n=4, k=1000, blending=False, blendrate=0.2,
+              mode=None, override=0, cylinderT=1, matches=None):
+    """Panorama pipeline of ransac.py:235-283: matches -> RANSAC homography -> warp + composite.
+    `matches=(ptsA, ptsB)` injects precomputed correspondences so the
+    GPU path works without OpenCV; everything else keeps the reference's signature."""
+    if override != 0:
+        import cv2
+        status, imgn = cv2.Stitcher_create().stitch([trainImg, queryImg])
+        return imgn
+    ptsA, ptsB = matches if matches is not None else _match_features(trainImg, queryImg)
+    ptsA = np.asarray(ptsA, dtype=np.float32)
+    ptsB = np.asarray(ptsB, dtype=np.float32)
+    if mode is None:
+        model = HomoModel(th=th, d=d, n=4)
+        H, inliers, _len = RANSAC(model, k=k).run([ptsA.T, ptsB.T], method=ransacMet)
+    else:
+        import cv2
+        H, status = cv2.findHomography(ptsA, ptsB, cv2.RANSAC, 4)
+    return stitchPanorama(queryImg, trainImg, H=H, blending=blending, blendrate=blendrate)

@@ -1,0 +1,80 @@
+"""CPU-only checks of the C ABI boundary: the library builds, loads, and exports every symbol
+include/rwh.h declares; argument validation works without a GPU; the product refuses to compute
+without one (no CPU fallback)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    g.build()
+    from ransac_with_homography_amd import _lib
+    return _lib.load()
+
+
+def test_exports_match_header(lib):
+    from ransac_with_homography_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "rwh.h")).read()
+    declared = set(re.findall(r"RWH_API\s+[\w\s\*]+?\b(rwh_\w+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS)
+    for name in declared:
+        assert getattr(lib, name) is not None
+    assert lib.rwh_abi_version() == 1
+    assert lib.rwh_strerror(-1) == b"invalid argument"
+
+
+def test_argument_validation_without_gpu(lib):
+    ih = (ctypes.c_double * 9)(1, 0, 0, 0, 1, 0, 0, 0, 1)
+    null = ctypes.c_void_p(0)
+    # NULL pointers -> RWH_E_INVALID before anything touches a device
+    st = lib.rwh_warp_backward(null, 10, 10, 3, 0, 300, 1, ih, 1, 0., 1., 9., 0., 1., 9., 10, 10, 10, 10, 1,
+                               null, 0, 300, 0, 10, 0, null)
+    assert st == -1
+    assert lib.rwh_dlt4_batched(null, null, 10, null, 4, null, null, null) == -1
+    assert lib.rwh_score_count(null, null, null, 10, 4, 5.0, 0, 3, 0, null, null, null, null, null) == -1
+    assert lib.rwh_project_points(null, null, 10, 0, null, null) == -1
+
+
+def test_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import homography as hg
+    import ransac as rs
+    from ransac_with_homography_amd import RwhUnavailable
+    with pytest.raises(RwhUnavailable):
+        hg.wrapPerspective(np.zeros((8, 8, 3), np.uint8), np.eye(3), "bilinear")
+    with pytest.raises(RwhUnavailable):
+        rs.RANSAC(rs.HomoModel(), k=10).run([np.zeros((2, 8), np.float32), np.zeros((2, 8), np.float32)], "fwd")
+
+
+def test_product_never_imports_oracle():
+    """The oracle is test infrastructure: nothing shipped may reference it."""
+    shipped = [os.path.join(ROOT, "homography.py"), os.path.join(ROOT, "ransac.py")]
+    pkg = os.path.join(ROOT, "ransac_with_homography_amd")
+    for d, _, files in os.walk(pkg):
+        shipped += [os.path.join(d, f) for f in files if f.endswith((".py", ".hip", ".h"))]
+    for path in shipped:
+        text = open(path).read()
+        assert not re.search(r"^\s*(from|import)\s+oracle\b", text, re.M), path
+
+
+def test_host_solvers_match_goldens():
+    """Host-side O(1) solvers of the product against the reference's G1 outputs."""
+    import homography as hg
+    from conftest import load_golden
+    z = load_golden("g1_fourpoint")
+    u, v = z["u"].T[:, :2], z["v"].T[:, :2]
+    A, b = hg.calc_correspLinear(u, v)
+    assert np.array_equal(A, z["A"]) and np.array_equal(b, z["b"])
+    assert np.array_equal(hg.calc_corresp(u, v), z["mat"])
+    assert np.array_equal(hg.calcHomographyLinear(u, v), z["H_linear"])
+    assert np.array_equal(hg.calcHomography(u, v), z["H_dlt"])          # float64 inputs: host SVD path
+    assert hg.calcH is hg.calcHomographyLinear and hg.perspectiveTransform is hg.wrapPerspective
