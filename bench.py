@@ -1,0 +1,188 @@
+#!/usr/bin/env python3
+"""bench.py -- backward-warp Mpixels/s (+ RANSAC hypotheses/s) on N MI355X of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
+  transformImageH-style warp of 3840x2160 RGB u8 frames with the survey's mild-perspective Hs,
+  bilinear, uint8 out (output 2028x3771 per frame, the reference's auto-bounds geometry).
+  One "step" = ONE launch of the warp kernel over a batch of FRAMES distinct frames already
+  resident in HBM (batch source + destination = 1.5 GB > the 256 MB Infinity Cache, so the
+  traffic is HBM traffic, not cache traffic).
+  N > 1: every rank warps its own batch (shard by image, no collective): weak scaling.
+Also reported in the same JSON line (extra keys): RANSAC hypotheses/s on matchespoints
+(10 000 hypotheses per GPU-step at N=1; 100 000 sharded over the ranks with the one
+all-reduce at N>1), the roofline of the dominant kernel, and the numpy CPU path timed on this
+box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+H_S = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+SRC_H, SRC_W = 2160, 3840
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+
+
+def cpu_baseline(frames_note):
+    """The numpy CPU path (oracle = bit-identical restatement of the reference) on ONE frame of the
+    same workload, min of 3 after 1 warm-up, single process (numpy's elementwise ops are single
+    threaded).  Plus the RANSAC loop body on 300 hypotheses."""
+    from oracle import rwh_oracle as orc
+    img = np.random.default_rng(1234).integers(0, 256, (SRC_H, SRC_W, 3), dtype=np.uint8)
+    ts = []
+    out = None
+    for i in range(3):
+        t0 = time.perf_counter()
+        out, _, _ = orc.transform_image_h(img, H_S)
+        ts.append(time.perf_counter() - t0)
+    t = min(ts[1:]) if len(ts) > 1 else ts[0]
+    mpix = out.shape[0] * out.shape[1] / 1e6
+    z = np.load(os.path.join(ROOT, "tests", "golden", "matchespoints.npz"))
+    X, Y = z["ptsA"].T, z["ptsB"].T
+    np.random.seed(0)
+    idx = np.random.randint(0, X.shape[1], (300, 4))
+    t0 = time.perf_counter()
+    orc.ransac_table(X, Y, idx, th=5, method="fwd")
+    tr = time.perf_counter() - t0
+    return {"value": round(mpix / t, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
+            "sample": "1 frame 3840x2160 RGB u8 -> %dx%d (of the %s), numpy oracle, min of 2 after warm-up; "
+                      "os.cpu_count=%d OPENBLAS_NUM_THREADS=%s" % (out.shape[0], out.shape[1], frames_note,
+                                                                   os.cpu_count(), os.environ.get("OPENBLAS_NUM_THREADS", "unset")),
+            "ransac_hyp_per_s": round(300 / tr, 1), "ransac_sample": "300 hypotheses x 185 correspondences, fwd"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--frames", type=int, default=32, help="4K frames per step (per GPU)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from ransac_with_homography_amd import kernels, sharded
+    from ransac_with_homography_amd.homography import _bounds
+
+    # ---- warp workload ---------------------------------------------------------------------
+    B = args.frames
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    src = torch.randint(0, 256, (B, SRC_H, SRC_W, 3), dtype=torch.uint8, device=dev, generator=gen)
+    min_x, min_y, out_w, out_h = _bounds(SRC_H, SRC_W, H_S, 0)
+    grid = kernels.Grid(min_x, min_x + out_w - 1, out_w, min_y, min_y + out_h - 1, out_h)
+    inv = np.linalg.inv(H_S)
+    dst = torch.empty((B, out_h, out_w, 3), dtype=torch.uint8, device=dev)
+
+    def step():
+        kernels.warp_backward(src, inv, grid, (SRC_H, SRC_W), "bilinear", torch.uint8, out=dst)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync_all()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps  # HIP events on the launch stream
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    mpix_step = B * out_h * out_w / 1e6
+    value = world * mpix_step * args.steps / elapsed
+
+    # ---- RANSAC workload -----------------------------------------------------------------------
+    z = np.load(os.path.join(ROOT, "tests", "golden", "matchespoints.npz"))
+    pa, pb = torch.from_numpy(z["ptsA"]).to(dev), torch.from_numpy(z["ptsB"]).to(dev)
+    K = 10000 if world == 1 else 100000
+    np.random.seed(0)
+    idx_table = np.random.randint(0, 185, (K, 4))
+    b, e = sharded.shard_range(K, rank, world)
+    idx_dev = torch.from_numpy(idx_table[b:e].astype(np.int32)).to(dev)
+    need = kernels.need_count(185, 70, 4)
+
+    def ransac_step():
+        best = kernels.new_best(dev)
+        Hs, _ = kernels.dlt4_batched(pa, pb, idx_dev)
+        kernels.score_count(Hs, pa, pb, 5.0, "fwd", need, best, hyp_base=b, want_masks=False)
+        if world > 1:
+            dist.all_reduce(best, op=dist.ReduceOp.MAX)
+        return best.cpu()  # the 16-byte result reaches the host: launch + readback latency included
+
+    for _ in range(3):
+        ransac_step()
+    sync_all()
+    t0 = time.perf_counter()
+    R = 20
+    for _ in range(R):
+        best = ransac_step()
+    sync_all()
+    tr = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([tr], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        tr = float(tt.item())
+    winner, cnt, early = kernels.decode_best(best.numpy(), K)
+
+    if rank == 0:
+        alg_bytes = B * (3 * SRC_H * SRC_W + 3 * out_h * out_w)
+        achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            traffic = json.load(open(tpath)).get("warp_rgb8_bilinear_u8_bytes_per_launch")
+        line = {
+            "metric": "backward-warp Mpixels/sec (+ RANSAC hypotheses/sec)", "value": round(value, 1), "unit": "Mpix/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 (f64 coordinates, f32 blend)", "data": "synthetic",
+            "config": {"workload": "transformImageH warp 3840x2160 RGB u8 bilinear -> %dx%d u8, %d distinct frames per "
+                                   "GPU per step, Hs mild perspective" % (out_h, out_w, B),
+                       "frames_per_step_per_gpu": B, "sharding": "by image, no collective"},
+            "roofline": {"bound": "hbm", "kernel": "warp_rgb8_bilinear<u8>", "achieved": round(achieved, 1),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                         "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms": round(kernel_ms, 4),
+                         "read_only_frac": round(B * 3 * SRC_H * SRC_W / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "ransac": {"hyp_per_s": round(K * R / tr, 1), "hypotheses": K, "correspondences": 185,
+                       "pair_evals_per_s": round(K * R * 185 / tr, 1), "winner": winner, "winner_count": cnt,
+                       "includes": "K1+K2 launches%s + 16-byte readback per run" % (" + all-reduce(max)" if world > 1 else "")},
+        }
+        if not args.no_cpu and world == 1:
+            line["cpu_baseline"] = cpu_baseline("%d-frame batch" % B)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

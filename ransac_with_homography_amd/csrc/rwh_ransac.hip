@@ -130,7 +130,7 @@ __device__ __forceinline__ void proj(const float (&h)[9], float x, float y, floa
     float a1 = h[3] * x; a1 = fmaf(h[4], y, a1); a1 = a1 + h[5];
     float a2 = h[6] * x; a2 = fmaf(h[7], y, a2); a2 = a2 + h[8];
     const float den = a2 + 1e-10f;
-    px = __fdiv_rn(a0, den); py = __fdiv_rn(a1, den); pw = __fdiv_rn(a2, den);
+    px = a0 / den; py = a1 / den; pw = a2 / den;  // IEEE: -fhip-fp32-correctly-rounded-divide-sqrt
 }
 
 __device__ __forceinline__ float proj_err(const float (&h)[9], float x, float y, float xp, float yp) {
@@ -138,7 +138,7 @@ __device__ __forceinline__ float proj_err(const float (&h)[9], float x, float y,
     proj(h, x, y, px, py, pw);
     const float dx = px - xp, dy = py - yp;
     const float s = dx * dx + dy * dy;
-    return __fsqrt_rn(s);
+    return sqrtf(s);  // correctly rounded (__fsqrt_rn would lower to the approximate native sqrt)
 }
 
 // float64 inverse of a float32 3x3 rounded back to float32 (numpy.linalg.inv on a float32 array,

@@ -342,9 +342,11 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
                                  void* d_dst, int dst_dtype, int64_t dst_image_stride,
                                  int row_begin, int row_end, unsigned flags, void* stream) {
     using namespace rwh;
-    if (!d_src || !d_dst || !inv_h) return RWH_E_INVALID;
-    if (src_h < 3 || src_w < 3 || batch <= 0 || out_h <= 0 || out_w <= 0) return RWH_E_INVALID;
+    if (batch <= 0 || out_h <= 0 || out_w <= 0) return RWH_E_INVALID;
     if (row_begin < 0 || row_end > out_h || row_begin > row_end) return RWH_E_INVALID;
+    if (row_begin == row_end) return RWH_OK;  // empty row tile (a rank with no rows): nothing to do
+    if (!d_src || !d_dst || !inv_h) return RWH_E_INVALID;
+    if (src_h < 3 || src_w < 3) return RWH_E_UNSUPPORTED;
     if (bound_h <= 0 || bound_w <= 0) return RWH_E_INVALID;
     if (interp != RWH_NEAREST && interp != RWH_BILINEAR) return RWH_E_INVALID;
     if (n_h != 1) return RWH_E_UNSUPPORTED;
@@ -352,7 +354,6 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     if (src_dtype != RWH_U8 && src_dtype != RWH_F32) return RWH_E_UNSUPPORTED;
     const size_t esz = src_dtype == RWH_U8 ? 1 : 4;
     if ((size_t)src_h * (size_t)src_w * channels * esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;
-    if (row_begin == row_end) return RWH_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
     if (flags & RWH_WARP_ZERO_ORIGIN) {

@@ -1,0 +1,79 @@
+"""Multi-GPU form of the path: one process per GPU, `torch.distributed` (backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).
+
+  * RANSAC shards the hypothesis index range [0, K) into contiguous slices, one per rank, over
+    replicated correspondences (3 KB).  Each rank reduces its slice to the two packed keys of
+    rwh_score_count; ONE all-reduce(MAX) of 2 x int64 yields the global winner with the reference's
+    first-index tie-break and early-exit semantics (ransac.py:186-202).  16 bytes: pure latency.
+  * The warp shards by output-row tiles (one image) or by image (a batch); rows and images are
+    independent, so there is NO collective on that path and outputs stay sharded.
+
+The scoring backend is injectable so that the sharding / reduction logic is testable on CPU
+ranks (the CPU tests plug the oracle in; the product default is the HIP kernels).
+"""
+import numpy as np
+
+
+def shard_range(total, rank, world):
+    """Contiguous slice [begin, end) of `total` items owned by `rank`; sizes differ by at most 1."""
+    base, rem = divmod(int(total), int(world))
+    begin = rank * base + min(rank, rem)
+    return begin, begin + base + (1 if rank < rem else 0)
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def gpu_score_slice(pa, pb, idx_slice, th, loss, need, hyp_base):
+    """Product backend: K1 + K2 on this rank's GPU.  Returns the 2 x int64 key tensor (on the GPU)."""
+    import torch
+    from . import kernels
+    best = kernels.new_best(pa.device)
+    if idx_slice.shape[0]:
+        idx = torch.from_numpy(np.ascontiguousarray(idx_slice, dtype=np.int32)).to(pa.device)
+        Hs, _ = kernels.dlt4_batched(pa, pb, idx)
+        kernels.score_count(Hs, pa, pb, th, loss, need, best, hyp_base=hyp_base, want_masks=False)
+    return best
+
+
+def ransac_sharded(pa, pb, idx_table, th, loss, need, score_slice=gpu_score_slice, group=None):
+    """Sharded hypothesis search.  `idx_table`: the full K x 4 host index table (every rank draws the
+    same table from the same seed).  Returns (winner_index | None, early_exit) on every rank."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    k = idx_table.shape[0]
+    b, e = shard_range(k, rank, world)
+    best = score_slice(pa, pb, idx_table[b:e], th, loss, need, b)
+    if not isinstance(best, torch.Tensor):
+        best = torch.as_tensor(np.asarray(best, dtype=np.int64))
+    if world > 1:
+        dist.all_reduce(best, op=dist.ReduceOp.MAX, group=group)  # the one collective of the path
+    from .kernels import decode_best
+    winner, _, early = decode_best(best.cpu().numpy(), k)
+    return winner, early
+
+
+def winner_inliers(pa, pb, idx_row, th, loss):
+    """Inlier indices of one hypothesis, recomputed locally by every rank (deterministic)."""
+    import torch
+    from . import kernels
+    idx = torch.from_numpy(np.ascontiguousarray(idx_row, dtype=np.int32).reshape(1, 4)).to(pa.device)
+    Hs, _ = kernels.dlt4_batched(pa, pb, idx)
+    counts, masks, _ = kernels.score_count(Hs, pa, pb, th, loss, 1 << 30, kernels.new_best(pa.device))
+    bits = np.unpackbits(masks[0].cpu().numpy().view(np.uint8), bitorder="little")[:pa.shape[0]]
+    return np.nonzero(bits)[0].astype(np.int64), int(counts[0])
+
+
+def warp_row_shard(src, inv_h, grid, bound_hw, interp, out_dtype, group=None):
+    """This rank's output-row tile of one warp: returns (tensor [rows, out_w, C], (row_begin, row_end)).
+    The source is replicated; nothing is exchanged."""
+    from . import kernels
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    rows = shard_range(grid.out_h, rank, world)
+    return kernels.warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, rows=rows), rows

