@@ -1,0 +1,322 @@
+// K3 fast path: RGB u8 source, bilinear, u8 (truncated) or f32 output -- the BASELINE configuration.
+//
+// What bounds this kernel on MI355X (measured): not HBM.  A direct gather
+// version (one lane = 4 output pixels, two unaligned 8-byte loads per pixel) is bound first by the
+// texture-address unit (a 64-lane gather costs ~16 cycles per dword per lane-quad, i.e. one TA cycle
+// per pixel per CU) and, once that is fixed, by VALU issue: every VALU instruction, float32 or
+// float64, costs ~4.2 cycles per wave on gfx950 and only v_pk_*_f32 does two lanes' worth per issue.
+// So the design goal is "few instructions per pixel", and loads that are wide and coalesced:
+//
+//   * one wave = a 64 x 4 output patch, one lane = 4 consecutive pixels of one patch row;
+//   * X, Y, W of a pixel are affine in (row, column): lane setup is two float64 FMAs per coordinate
+//     from host-precomputed coefficients, the lane's other three pixels are one add each;
+//   * ONE v_rcp_f64 per lane: its four W are inverted together (Montgomery batch inversion);
+//   * floor / fraction / weights come from the float64 "magic number" u = s + 1.5*2^20 (ulp 2^-32):
+//     hi(u) - 0x41380000 = floor(s), lo(u) = frac(s) * 2^32; w = cvt(lo) and 1-w = cvt(~lo) are both
+//     correct to float32 rounding; the 2^-64 scale of (x weight)*(y weight) rides on the y weights;
+//   * the patch's source footprint is the bounding box of its four mapped corners (extremes of a
+//     projective map over a rectangle sit at the corners while W keeps its sign); if it lies strictly
+//     inside the image the wave needs NO per-pixel bounds logic, and it copies the footprint into a
+//     wave-private LDS slab with coalesced 12-byte loads (21 lanes per source row, 3 rows per
+//     instruction), expanding RGB to 4-byte RGBX texels so that the bilinear taps are 4-byte aligned
+//     ds_read2_b32 pairs (8-byte LDS reads at 4-byte alignment stall as "unaligned");
+//   * waves that touch the border, cross the horizon, or have a footprint that does not fit the slab
+//     (strong zoom-out / rotation) take a masked gather path straight from global memory, with a
+//     byte-exact guard for the last source rows so nothing is read past the image;
+//   * the blend is the 4-weight form on packed float32 pairs (pixel j | pixel j+1);
+//   * u8 output: v_cvt_pk_u8_f32 converts + packs a byte per instruction; it rounds to nearest, so the
+//     accumulator starts at -0.5 + 2^-15: exact integers (weights 0/1) land on themselves, anything else
+//     is floor(v + 3e-5), inside the float32 blend's own noise.
+// No MFMA: there is no dense contraction on this path.
+#pragma once
+#include "rwh_common.h"
+
+namespace rwh {
+
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+constexpr double MAGIC = 1572864.0;                   // 1.5 * 2^20: ulp(MAGIC + s) = 2^-32 for |s| < 2^19
+constexpr uint32_t MAGIC_HI = 0x41380000u;            // high dword of MAGIC
+constexpr unsigned long long MAGIC_BITS = 0x4138000000000000ull;
+constexpr float W_SCALE = 5.42101086242752217e-20f;   // 2^-64
+constexpr float U8_BIAS = -0.5f + 3.0517578125e-05f;  // -0.5 + 2^-15, see above
+
+constexpr int FP_PX = 4;                               // pixels per lane
+constexpr int FP_ROWS = 9;                             // source rows a wave can stage (3 per staging step)
+constexpr int FP_LANES = 21;                           // staging lanes per source row, 4 texels (12 B) each
+constexpr int FP_TEXELS = 4 * FP_LANES;                // 84 texels per staged row
+constexpr int FP_PITCH = 4 * FP_TEXELS + 16;           // 352 B per staged row of RGBX texels (+16: bank stagger)
+
+struct FastArgs {
+    const unsigned char* src;
+    unsigned char* dst;
+    long long src_img_stride, dst_img_stride;            // bytes
+    // X = cx[0] + row*cx[1] + col*cx[2] for output (row, col); likewise Y, W   (float64, host-built)
+    double cx[3], cy[3], cw[3];
+    double dxs[3][3];                                    // dxs[j-1] = j * (cx[2], cy[2], cw[2])
+    unsigned long long xmax_bits, ymax_bits;             // bit patterns of MAGIC + (bound_w-1), MAGIC + (bound_h-1)
+    int src_h, src_w, bound_h, bound_w, out_w;
+    int row_begin, rows;                                 // produce output rows [row_begin, row_begin+rows)
+    unsigned tiles_x, tiles_y, nblocks, cpx;
+    unsigned tiles_x_magic, tiles_y_magic;               // floor(n/d) = umulhi(n, magic) for n < nblocks
+};
+
+__device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_as_longlong(v) >> 32); }
+__device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)__double_as_longlong(v); }
+__device__ __forceinline__ float ubyte(uint32_t v, int byte) { return (float)((v >> (8 * byte)) & 0xffu); }
+
+// Blend 4 pixels (taps a0 = texel(iy,ix), b0 = texel(iy,ix+1), a1/b1 = row iy+1; R,G,B in bytes 0..2)
+// and store them.  `full`: the lane owns all 4 pixels; otherwise it owns local pixels j >= shift.
+template <typename DstT>
+__device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
+                                            const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
+                                            const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
+                                            const float (&wy0)[FP_PX], const float (&wy1)[FP_PX],
+                                            DstT* drow, bool store_any, int shift) {
+    constexpr bool U8 = sizeof(DstT) == 1;
+    constexpr float BIAS = U8 ? U8_BIAS : 0.f;
+    float o[FP_PX][3];
+#pragma unroll
+    for (int j = 0; j < FP_PX; j += 2) {
+        const f2 WX0 = {wx0[j], wx0[j + 1]}, WX1 = {wx1[j], wx1[j + 1]};
+        const f2 WY0 = {wy0[j], wy0[j + 1]}, WY1 = {wy1[j], wy1[j + 1]};
+        const f2 W00 = WX0 * WY0, W01 = WX1 * WY0, W10 = WX0 * WY1, W11 = WX1 * WY1;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const f2 P00 = {ubyte(a0[j], k), ubyte(a0[j + 1], k)}, P01 = {ubyte(b0[j], k), ubyte(b0[j + 1], k)};
+            const f2 P10 = {ubyte(a1[j], k), ubyte(a1[j + 1], k)}, P11 = {ubyte(b1[j], k), ubyte(b1[j + 1], k)};
+            f2 acc = __builtin_elementwise_fma(P00, W00, f2{BIAS, BIAS});
+            acc = __builtin_elementwise_fma(P01, W01, acc);
+            acc = __builtin_elementwise_fma(P10, W10, acc);
+            acc = __builtin_elementwise_fma(P11, W11, acc);
+            o[j][k] = acc.x; o[j + 1][k] = acc.y;
+        }
+    }
+    if (!store_any) return;
+    if (shift == 0) {
+        if constexpr (U8) {
+            pk3 w;
+            uint32_t q = 0;
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][0], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][1], 1, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][2], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][0], 3, q);
+            w.a = q; q = 0;
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][1], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][2], 1, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][0], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][1], 3, q);
+            w.b = q; q = 0;
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][2], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][0], 1, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][1], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][2], 3, q);
+            w.c = q;
+            __builtin_memcpy(drow, &w, 12);
+        } else {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const float* f = &o[0][0] + 4 * v;
+                pk4 w = {__float_as_uint(f[0]), __float_as_uint(f[1]), __float_as_uint(f[2]), __float_as_uint(f[3])};
+                __builtin_memcpy(reinterpret_cast<unsigned char*>(drow) + 16 * v, &w, 16);
+            }
+        }
+    } else {  // the one straddling lane of a ragged row
+#pragma unroll
+        for (int j = 1; j < FP_PX; ++j)
+            if (j >= shift) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    if constexpr (U8) drow[3 * j + k] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(o[j][k], 0, 0);
+                    else drow[3 * j + k] = o[j][k];
+                }
+            }
+    }
+}
+
+template <typename DstT>
+__global__ __launch_bounds__(256) void warp_rgb8_fast(const FastArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * FP_PITCH];
+
+    // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
+    const unsigned b = blockIdx.x;
+    const unsigned logical = (b & 7u) * a.cpx + (b >> 3);   // XCD k walks logical blocks [k*cpx, (k+1)*cpx)
+    if (logical >= a.nblocks) return;
+    const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;   // magic 0 <=> divisor 1
+    const unsigned tx = logical - t * a.tiles_x;
+    const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
+    const unsigned ty = t - img * a.tiles_y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int prow = lane >> 4, pq = lane & 15;               // patch row 0..3, 4-pixel column group 0..15
+
+    const int rr_raw = (int)ty * 4 + prow;
+    const int rr = min(rr_raw, a.rows - 1);                   // rows past the shard recompute its last row
+    const int c0 = ((int)tx * 4 + wave) * 64 + pq * FP_PX;
+    const int c0p = min(c0, a.out_w - FP_PX);                 // columns past the row end recompute its last 4 px
+    const int shift = c0 - c0p;
+    const bool store_any = (rr_raw < a.rows) & (c0 < a.out_w);
+
+    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;       // uniform
+    unsigned char* dimg = a.dst + (long long)img * a.dst_img_stride;              // uniform
+    // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
+    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
+
+    // ---- source coordinates of the lane's 4 pixels -----------------------------------------------
+    const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
+    double X[FP_PX], Y[FP_PX], W[FP_PX];
+    X[0] = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
+    Y[0] = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
+    W[0] = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+#pragma unroll
+    for (int j = 1; j < FP_PX; ++j) {
+        X[j] = X[0] + a.dxs[j - 1][0];
+        Y[j] = Y[0] + a.dxs[j - 1][1];
+        W[j] = W[0] + a.dxs[j - 1][2];
+    }
+    double rc[FP_PX];
+    // W is affine along a row, so W[0] > 0 and W[3] > 0 make all four positive; with a finite, normal product
+    // the four reciprocals come from ONE v_rcp_f64 (Montgomery batch inversion).  `wpos` is wave-uniform.
+    const double p01 = W[0] * W[1], p23 = W[2] * W[3], P = p01 * p23;
+    const bool wpos = __all(__builtin_amdgcn_class(P, 0x100) & ((int)hi32(W[0]) > 0) & ((int)hi32(W[FP_PX - 1]) > 0));
+    if (wpos) {
+        double rp = __builtin_amdgcn_rcp(P);
+        rp = fma(fma(-P, rp, 1.0), rp, rp);
+        const double r01 = rp * p23, r23 = rp * p01;
+        rc[0] = r01 * W[1]; rc[1] = r01 * W[0]; rc[2] = r23 * W[3]; rc[3] = r23 * W[2];
+    } else {                                                      // a W at / across zero (the horizon): pixel by pixel
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            double q = __builtin_amdgcn_rcp(W[j]);
+            rc[j] = fma(fma(-W[j], q, 1.0), q, q);
+        }
+    }
+    uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
+    unsigned long long ubx[FP_PX], uby[FP_PX];
+#pragma unroll
+    for (int j = 0; j < FP_PX; ++j) {
+        const double ux = X[j] * rc[j] + MAGIC;
+        const double uy = Y[j] * rc[j] + MAGIC;
+        ubx[j] = (unsigned long long)__double_as_longlong(ux);
+        uby[j] = (unsigned long long)__double_as_longlong(uy);
+        lx[j] = lo32(ux); ly[j] = lo32(uy);
+        hx[j] = hi32(ux); hy[j] = hi32(uy);
+    }
+    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+
+    // ---- wave-uniform footprint from the four patch corners (lanes 0, 15, 48, 63), on the scalar unit ----
+    // hi dwords compare like the integers they encode (same exponent); out-of-range / NaN corners end up
+    // as the min or the max and fail the range test below.
+    const int x0 = (int)__builtin_amdgcn_readlane(hx[0], 0), x1 = (int)__builtin_amdgcn_readlane(hx[FP_PX - 1], 15);
+    const int x2 = (int)__builtin_amdgcn_readlane(hx[0], 48), x3 = (int)__builtin_amdgcn_readlane(hx[FP_PX - 1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(hy[0], 0), y1 = (int)__builtin_amdgcn_readlane(hy[FP_PX - 1], 15);
+    const int y2 = (int)__builtin_amdgcn_readlane(hy[0], 48), y3 = (int)__builtin_amdgcn_readlane(hy[FP_PX - 1], 63);
+    const int xa = min(x0, x1), xb = min(x2, x3), xc = max(x0, x1), xd = max(x2, x3);
+    const int ya = min(y0, y1), yb = min(y2, y3), yc = max(y0, y1), yd = max(y2, y3);
+    const int hxmn = __builtin_amdgcn_readfirstlane(min(xa, xb)), hxmx = __builtin_amdgcn_readfirstlane(max(xc, xd));
+    const int hymn = __builtin_amdgcn_readfirstlane(min(ya, yb)), hymx = __builtin_amdgcn_readfirstlane(max(yc, yd));
+    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
+    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row,
+    // and the footprint (rows ymn..ymx+1, texels xmn..xmx+1) fits the slab
+    const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) &
+                        (ymx < min(a.bound_h - 1, a.src_h - 2)) & (ymx - ymn + 2 <= FP_ROWS) & (xmx - xmn + 2 <= FP_TEXELS);
+
+    uint32_t a0[FP_PX], b0[FP_PX], a1[FP_PX], b1[FP_PX];
+    float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
+    if (staged) {
+        const int nrows = ymx - ymn + 2, ntex = xmx - xmn + 2;
+        unsigned char* my = slab[wave];
+        // staging lane -> (source row srow of 3, texel group scol of 21): 12 packed bytes in, 4 RGBX texels out
+        const int srow = (lane * 49) >> 10;                     // lane / 21 for lane < 64
+        const int scol = lane - FP_LANES * srow;
+        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+        const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 12u;
+        unsigned char* wlds = my + srow * FP_PITCH + scol * 16;
+        const bool mine = (srow < 3) & (4 * scol < ntex);
+        // all staging loads are issued before the first LDS write so that their latencies overlap
+        pk3 v[FP_ROWS / 3];
+        bool on[FP_ROWS / 3];
+#pragma unroll
+        for (int k = 0; k < FP_ROWS / 3; ++k) {
+            on[k] = mine & (3 * k + srow < nrows);
+            v[k] = pk3{0u, 0u, 0u};
+            if (on[k]) __builtin_memcpy(&v[k], gbase + (size_t)(3 * k) * pitch + goff, 12);
+        }
+        // weights and LDS addresses while the loads fly
+        const uint32_t lds_c = (uint32_t)hymn * (uint32_t)FP_PITCH + (uint32_t)hxmn * 4u;  // uniform
+        uint32_t lo[FP_PX];
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
+            wy1[j] = (float)ly[j] * W_SCALE; wy0[j] = (float)(~ly[j]) * W_SCALE;
+            lo[j] = hy[j] * (uint32_t)FP_PITCH + hx[j] * 4u - lds_c;
+        }
+#pragma unroll
+        for (int k = 0; k < FP_ROWS / 3; ++k) {
+            if (on[k]) {
+                uint4 t4;
+                t4.x = v[k].a;
+                t4.y = __builtin_amdgcn_alignbyte(v[k].b, v[k].a, 3);
+                t4.z = __builtin_amdgcn_alignbyte(v[k].c, v[k].b, 2);
+                t4.w = v[k].c >> 8;
+                *reinterpret_cast<uint4*>(wlds + 3 * k * FP_PITCH) = t4;
+            }
+        }
+        // the slab is wave-private: order this wave's LDS writes before its LDS reads, no block barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            // two dwords at a 4-byte aligned address: ds_read2_b32 (a ds_read_b64 here is "unaligned" and stalls)
+            const uint32_t* t0 = reinterpret_cast<const uint32_t*>(my + lo[j]);
+            a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t0[FP_PITCH / 4]; b1[j] = t0[FP_PITCH / 4 + 1];
+        }
+        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow, store_any, shift);
+        return;
+    }
+
+    // ---- border / oversize waves: masked gathers from global memory -----------------------------------
+    uint32_t off[FP_PX];
+    bool near_end = false;
+#pragma unroll
+    for (int j = 0; j < FP_PX; ++j) {
+        // 0 <= s <= bound-1 on the bit patterns: positive doubles order like unsigned integers; negative
+        // values and NaNs have patterns outside [MAGIC_BITS, xmax_bits]
+        const bool valid = (ubx[j] >= MAGIC_BITS) & (ubx[j] <= a.xmax_bits) & (uby[j] >= MAGIC_BITS) & (uby[j] <= a.ymax_bits);
+        const float sc = valid ? W_SCALE : 0.f;
+        const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
+        wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
+        wy1[j] = (float)ly[j] * sc; wy0[j] = (float)(~ly[j]) * sc;
+        off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
+        near_end |= valid & (iy > a.src_h - 3);
+    }
+    if (!__any(near_end)) {
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            const pk2 r0 = ld8(simg + off[j]);
+            const pk2 r1 = ld8(simg + off[j] + pitch);
+            a0[j] = r0.a; b0[j] = __builtin_amdgcn_alignbyte(r0.b, r0.a, 3);
+            a1[j] = r1.a; b1[j] = __builtin_amdgcn_alignbyte(r1.b, r1.a, 3);
+        }
+    } else {  // byte-exact loads, +1 taps clamped to the image (their weight is 0 when clamped)
+        const uint32_t last = (uint32_t)a.src_h * pitch - 3u;
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            const uint32_t o00 = off[j];
+            const uint32_t o01 = min(o00 + 3u, last), o10 = min(o00 + pitch, last), o11 = min(o00 + pitch + 3u, last);
+            a0[j] = simg[o00] | (simg[o00 + 1] << 8) | (simg[o00 + 2] << 16);
+            b0[j] = simg[o01] | (simg[o01 + 1] << 8) | (simg[o01 + 2] << 16);
+            a1[j] = simg[o10] | (simg[o10 + 1] << 8) | (simg[o10 + 2] << 16);
+            b1[j] = simg[o11] | (simg[o11 + 1] << 8) | (simg[o11 + 2] << 16);
+        }
+    }
+    blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow, store_any, shift);
+}
+
+// floor(n / d) == umulhi(n, magic) for every n < n_max, or 0 if no such 32-bit magic exists
+inline unsigned div_magic(unsigned d, unsigned long long n_max) {
+    if (d == 1) return 0;  // caller special-cases d == 1 (umulhi cannot express the identity)
+    const unsigned long long m = (1ull << 32) / d + 1;
+    // error term: n * (m*d - 2^32) < 2^32 must hold for all n < n_max
+    const unsigned long long e = m * d - (1ull << 32);
+    if (m >= (1ull << 32) || e * n_max >= (1ull << 32)) return 0;
+    return (unsigned)m;
+}
+
+}  // namespace rwh
