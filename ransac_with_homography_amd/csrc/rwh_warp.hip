@@ -197,24 +197,29 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 }
 
 // Fast-path launch (RGB u8, bilinear): returns RWH_E_UNSUPPORTED when the shape needs the generic kernel.
+// px8: 8 pixels per lane (128 x 16 block tiles) instead of 4 (256 x 4).
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
-                int dst_dtype, int batch, hipStream_t s) {
-    if (w.out_w < FP_PX || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
+                int dst_dtype, int batch, hipStream_t s, bool px8) {
+    const int lane_px = px8 ? F8_PX : FP_PX;
+    if (w.out_w < lane_px || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
+    const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
+    if ((size_t)w.rows * (size_t)w.out_w * 3 * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
     FastArgs a;
     a.src = w.src; a.dst = w.dst; a.src_img_stride = w.src_img_stride; a.dst_img_stride = w.dst_img_stride;
     a.cx[0] = ih[0] * x0 + ih[1] * y0 + ih[2]; a.cx[1] = ih[1] * step_y; a.cx[2] = ih[0] * step_x;
     a.cy[0] = ih[3] * x0 + ih[4] * y0 + ih[5]; a.cy[1] = ih[4] * step_y; a.cy[2] = ih[3] * step_x;
     a.cw[0] = ih[6] * x0 + ih[7] * y0 + ih[8]; a.cw[1] = ih[7] * step_y; a.cw[2] = ih[6] * step_x;
-    for (int j = 1; j <= 3; ++j) {
-        a.dxs[j - 1][0] = (double)j * a.cx[2]; a.dxs[j - 1][1] = (double)j * a.cy[2]; a.dxs[j - 1][2] = (double)j * a.cw[2];
+    for (int j = 1; j <= 7; ++j) {
+        const double d[3] = {(double)j * a.cx[2], (double)j * a.cy[2], (double)j * a.cw[2]};
+        for (int q = 0; q < 3; ++q) { a.dxs8[j - 1][q] = d[q]; if (j <= 3) a.dxs[j - 1][q] = d[q]; }
     }
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
     __builtin_memcpy(&a.ymax_bits, &ym, 8);
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
     a.row_begin = w.row_begin; a.rows = w.rows;
-    a.tiles_x = (unsigned)((w.out_w + 255) / 256);
-    a.tiles_y = (unsigned)((w.rows + 3) / 4);
+    a.tiles_x = (unsigned)(px8 ? (w.out_w + 127) / 128 : (w.out_w + 255) / 256);
+    a.tiles_y = (unsigned)(px8 ? (w.rows + 15) / 16 : (w.rows + 3) / 4);
     const unsigned long long nb = (unsigned long long)a.tiles_x * a.tiles_y * (unsigned)batch;
     if (nb >= (1ull << 31) / 8) return RWH_E_UNSUPPORTED;
     a.nblocks = (unsigned)nb;
@@ -222,8 +227,14 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.tiles_x_magic = div_magic(a.tiles_x, nb);
     a.tiles_y_magic = div_magic(a.tiles_y, nb / a.tiles_x + 1);
     if ((a.tiles_x > 1 && !a.tiles_x_magic) || (a.tiles_y > 1 && !a.tiles_y_magic)) return RWH_E_UNSUPPORTED;
-    if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_fast<unsigned char>, dim3(8u * a.cpx), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(warp_rgb8_fast<float>, dim3(8u * a.cpx), dim3(256), 0, s, a);
+    const dim3 grid(8u * a.cpx), block(256);
+    if (px8) {
+        if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_fast8<unsigned char>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(warp_rgb8_fast8<float>, grid, block, 0, s, a);
+    } else {
+        if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_fast<unsigned char>, grid, block, 0, s, a);
+        else hipLaunchKernelGGL(warp_rgb8_fast<float>, grid, block, 0, s, a);
+    }
     return check_launch();
 }
 
@@ -278,7 +289,7 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     a.cpx = (a.nblocks + 7u) / 8u;
 
     if (src_dtype == RWH_U8 && channels == 3 && interp == RWH_BILINEAR && (dst_dtype == RWH_U8 || dst_dtype == RWH_F32)) {
-        const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s);
+        const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*px8=*/a.out_w >= 128);
         if (st != RWH_E_UNSUPPORTED) return st;  // else: shape outside the fast kernel's limits -> generic kernel
     }
 

@@ -54,6 +54,7 @@ struct FastArgs {
     // X = cx[0] + row*cx[1] + col*cx[2] for output (row, col); likewise Y, W   (float64, host-built)
     double cx[3], cy[3], cw[3];
     double dxs[3][3];                                    // dxs[j-1] = j * (cx[2], cy[2], cw[2])
+    double dxs8[7][3];                                   // same for the 8-pixel-per-lane kernel
     unsigned long long xmax_bits, ymax_bits;             // bit patterns of MAGIC + (bound_w-1), MAGIC + (bound_h-1)
     int src_h, src_w, bound_h, bound_w, out_w;
     int row_begin, rows;                                 // produce output rows [row_begin, row_begin+rows)
@@ -93,6 +94,9 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
         }
     }
     if (!store_any) return;
+#ifdef RWH_ABL_NOSTORE  // tools/warp_lab ablation hook (never defined in the product build)
+    if (o[0][0] + o[1][1] + o[2][2] + o[3][0] != -12345.f) return;
+#endif
     if (shift == 0) {
         if constexpr (U8) {
             pk3 w;
@@ -128,8 +132,11 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
     }
 }
 
+#ifndef RWH_F4_WAVES
+#define RWH_F4_WAVES 8   // fits in 62 VGPRs without spilling: 8 waves per SIMD
+#endif
 template <typename DstT>
-__global__ __launch_bounds__(256) void warp_rgb8_fast(const FastArgs a) {
+__global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * FP_PITCH];
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void warp_rgb8_fast(const FastArgs a) {
     // W is affine along a row, so W[0] > 0 and W[3] > 0 make all four positive; with a finite, normal product
     // the four reciprocals come from ONE v_rcp_f64 (Montgomery batch inversion).  `wpos` is wave-uniform.
     const double p01 = W[0] * W[1], p23 = W[2] * W[3], P = p01 * p23;
-    const bool wpos = __all(__builtin_amdgcn_class(P, 0x100) & ((int)hi32(W[0]) > 0) & ((int)hi32(W[FP_PX - 1]) > 0));
+    const bool wpos = __all((int)__builtin_amdgcn_class(P, 0x100) & (int)((int)hi32(W[0]) > 0) & (int)((int)hi32(W[FP_PX - 1]) > 0));
     if (wpos) {
         double rp = __builtin_amdgcn_rcp(P);
         rp = fma(fma(-P, rp, 1.0), rp, rp);
@@ -307,6 +314,220 @@ __global__ __launch_bounds__(256) void warp_rgb8_fast(const FastArgs a) {
         }
     }
     blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow, store_any, shift);
+}
+
+
+// ---- 8 pixels per lane: one wave = a 128 x 4 output patch, one block = 4 waves stacked vertically (128 x 16) ----
+// Same arithmetic as warp_rgb8_fast, but the per-lane overhead (patch decode, coordinate setup, footprint,
+// staging set-up) is shared by twice as many pixels.
+constexpr int F8_PX = 8;
+constexpr int F8_LANES = 21;                           // staging lanes per source row, 8 texels (24 B) each
+constexpr int F8_TEXELS = 8 * F8_LANES;                // 168 texels per staged row
+constexpr int F8_PITCH = 4 * F8_TEXELS + 16;           // 688 B per staged row
+
+#ifndef RWH_F8_WAVES
+#define RWH_F8_WAVES 1
+#endif
+template <typename DstT>
+__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * F8_PITCH];
+
+    // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
+    const unsigned b = blockIdx.x;
+    const unsigned logical = (b & 7u) * a.cpx + (b >> 3);   // XCD k walks logical blocks [k*cpx, (k+1)*cpx)
+    if (logical >= a.nblocks) return;
+    const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;   // magic 0 <=> divisor 1
+    const unsigned tx = logical - t * a.tiles_x;
+    const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
+    const unsigned ty = t - img * a.tiles_y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int prow = lane >> 4, pq = lane & 15;               // patch row 0..3, 4-pixel column group 0..15
+
+    const int rr_raw = ((int)ty * 4 + wave) * 4 + prow;
+    const int rr = min(rr_raw, a.rows - 1);                   // rows past the shard recompute its last row
+    const int c0 = (int)tx * 128 + pq * F8_PX;
+    const int c0p = min(c0, a.out_w - F8_PX);                 // columns past the row end recompute its last 8 px
+    const int shift = c0 - c0p;
+    const bool store_any = (rr_raw < a.rows) & (c0 < a.out_w);
+
+    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;       // uniform
+    unsigned char* dimg = a.dst + (long long)img * a.dst_img_stride;              // uniform
+    // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
+    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
+
+    // ---- source coordinates of the lane's 4 pixels -----------------------------------------------
+    const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
+    double X[F8_PX], Y[F8_PX], W[F8_PX];
+    X[0] = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
+    Y[0] = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
+    W[0] = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+#pragma unroll
+    for (int j = 1; j < F8_PX; ++j) {
+        X[j] = X[0] + a.dxs8[j - 1][0];
+        Y[j] = Y[0] + a.dxs8[j - 1][1];
+        W[j] = W[0] + a.dxs8[j - 1][2];
+    }
+    double rc[F8_PX];
+    // W is affine along a row, so W[0] > 0 and W[7] > 0 make all eight positive; with a finite, normal product
+    // the eight reciprocals come from ONE v_rcp_f64 (Montgomery batch inversion).  `wpos` is wave-uniform.
+    const double p01 = W[0] * W[1], p23 = W[2] * W[3], p45 = W[4] * W[5], p67 = W[6] * W[7];
+    const double pa = p01 * p23, pb = p45 * p67, P = pa * pb;
+    const bool wpos = __all((int)__builtin_amdgcn_class(P, 0x100) & (int)((int)hi32(W[0]) > 0) & (int)((int)hi32(W[F8_PX - 1]) > 0));
+    if (wpos) {
+        double rp = __builtin_amdgcn_rcp(P);
+        rp = fma(fma(-P, rp, 1.0), rp, rp);
+        const double ra = rp * pb, rb = rp * pa;              // 1/pa, 1/pb
+        const double r01 = ra * p23, r23 = ra * p01, r45 = rb * p67, r67 = rb * p45;
+        rc[0] = r01 * W[1]; rc[1] = r01 * W[0]; rc[2] = r23 * W[3]; rc[3] = r23 * W[2];
+        rc[4] = r45 * W[5]; rc[5] = r45 * W[4]; rc[6] = r67 * W[7]; rc[7] = r67 * W[6];
+    } else {                                                      // a W at / across zero (the horizon): pixel by pixel
+#pragma unroll
+        for (int j = 0; j < F8_PX; ++j) {
+            double q = __builtin_amdgcn_rcp(W[j]);
+            rc[j] = fma(fma(-W[j], q, 1.0), q, q);
+        }
+    }
+    uint32_t lx[F8_PX], ly[F8_PX], hx[F8_PX], hy[F8_PX];
+    unsigned long long ubx[F8_PX], uby[F8_PX];
+#pragma unroll
+    for (int j = 0; j < F8_PX; ++j) {
+        const double ux = X[j] * rc[j] + MAGIC;
+        const double uy = Y[j] * rc[j] + MAGIC;
+        ubx[j] = (unsigned long long)__double_as_longlong(ux);
+        uby[j] = (unsigned long long)__double_as_longlong(uy);
+        lx[j] = lo32(ux); ly[j] = lo32(uy);
+        hx[j] = hi32(ux); hy[j] = hi32(uy);
+    }
+    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+
+    // ---- wave-uniform footprint from the four patch corners (lanes 0, 15, 48, 63), on the scalar unit ----
+    // hi dwords compare like the integers they encode (same exponent); out-of-range / NaN corners end up
+    // as the min or the max and fail the range test below.
+    const int x0 = (int)__builtin_amdgcn_readlane(hx[0], 0), x1 = (int)__builtin_amdgcn_readlane(hx[F8_PX - 1], 15);
+    const int x2 = (int)__builtin_amdgcn_readlane(hx[0], 48), x3 = (int)__builtin_amdgcn_readlane(hx[F8_PX - 1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(hy[0], 0), y1 = (int)__builtin_amdgcn_readlane(hy[F8_PX - 1], 15);
+    const int y2 = (int)__builtin_amdgcn_readlane(hy[0], 48), y3 = (int)__builtin_amdgcn_readlane(hy[F8_PX - 1], 63);
+    const int xa = min(x0, x1), xb = min(x2, x3), xc = max(x0, x1), xd = max(x2, x3);
+    const int ya = min(y0, y1), yb = min(y2, y3), yc = max(y0, y1), yd = max(y2, y3);
+    const int hxmn = __builtin_amdgcn_readfirstlane(min(xa, xb)), hxmx = __builtin_amdgcn_readfirstlane(max(xc, xd));
+    const int hymn = __builtin_amdgcn_readfirstlane(min(ya, yb)), hymx = __builtin_amdgcn_readfirstlane(max(yc, yd));
+    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
+    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row,
+    // and the footprint (rows ymn..ymx+1, texels xmn..xmx+1) fits the slab
+    const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) &
+                        (ymx < min(a.bound_h - 1, a.src_h - 2)) & (ymx - ymn + 2 <= FP_ROWS) & (xmx - xmn + 2 <= F8_TEXELS);
+
+    uint32_t a0[FP_PX], b0[FP_PX], a1[FP_PX], b1[FP_PX];
+    float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
+    if (staged) {
+        const int nrows = ymx - ymn + 2, ntex = xmx - xmn + 2;
+        unsigned char* my = slab[wave];
+        // staging lane -> (source row srow of 3, texel group scol of 21): 24 packed bytes in, 8 RGBX texels out
+        const int srow = (lane * 49) >> 10;                     // lane / 21 for lane < 64
+        const int scol = lane - F8_LANES * srow;
+        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+        const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 24u;
+        unsigned char* wlds = my + srow * F8_PITCH + scol * 32;
+        const bool mine = (srow < 3) & (8 * scol < ntex);
+        // all staging loads are issued before the first LDS write so that their latencies overlap
+        pk4 va[FP_ROWS / 3];
+        pk2 vb[FP_ROWS / 3];
+        bool on[FP_ROWS / 3];
+#pragma unroll
+        for (int k = 0; k < FP_ROWS / 3; ++k) {
+            on[k] = mine & (3 * k + srow < nrows);
+            va[k] = pk4{0u, 0u, 0u, 0u}; vb[k] = pk2{0u, 0u};
+#ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
+            va[k] = pk4{goff, goff * 3u, goff * 5u, goff * 7u}; vb[k] = pk2{goff * 11u, goff * 13u};
+#else
+            if (on[k]) {
+                __builtin_memcpy(&va[k], gbase + (size_t)(3 * k) * pitch + goff, 16);
+                __builtin_memcpy(&vb[k], gbase + (size_t)(3 * k) * pitch + goff + 16, 8);
+            }
+#endif
+        }
+        const uint32_t lds_c = (uint32_t)hymn * (uint32_t)F8_PITCH + (uint32_t)hxmn * 4u;  // uniform
+#pragma unroll
+        for (int k = 0; k < FP_ROWS / 3; ++k) {
+            if (on[k]) {
+                uint4 t4, t5;
+                t4.x = va[k].a;
+                t4.y = __builtin_amdgcn_alignbyte(va[k].b, va[k].a, 3);
+                t4.z = __builtin_amdgcn_alignbyte(va[k].c, va[k].b, 2);
+                t4.w = va[k].c >> 8;
+                t5.x = va[k].d;
+                t5.y = __builtin_amdgcn_alignbyte(vb[k].a, va[k].d, 3);
+                t5.z = __builtin_amdgcn_alignbyte(vb[k].b, vb[k].a, 2);
+                t5.w = vb[k].b >> 8;
+                *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH) = t4;
+                *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH + 16) = t5;
+            }
+        }
+        // the slab is wave-private: order this wave's LDS writes before its LDS reads, no block barrier
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                           // two halves of 4 pixels: registers are reused
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const int q = 4 * h + j;
+                wx1[j] = (float)lx[q]; wx0[j] = (float)(~lx[q]);
+                wy1[j] = (float)ly[q] * W_SCALE; wy0[j] = (float)(~ly[q]) * W_SCALE;
+                const uint32_t lo = hy[q] * (uint32_t)F8_PITCH + hx[q] * 4u - lds_c;
+#ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
+                a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
+#else
+                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(my + lo);
+                a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t0[F8_PITCH / 4]; b1[j] = t0[F8_PITCH / 4 + 1];
+#endif
+            }
+            // lane owns local pixels q >= shift; a half is stored whole when shift <= 4*h
+            blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 12 * h, store_any & (shift < 4 * h + 4), max(shift - 4 * h, 0));
+        }
+        return;
+    }
+
+    // ---- border / oversize waves: masked gathers from global memory -----------------------------------
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t off[FP_PX];
+        bool near_end = false;
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            const int q = 4 * h + j;
+            const bool valid = (ubx[q] >= MAGIC_BITS) & (ubx[q] <= a.xmax_bits) & (uby[q] >= MAGIC_BITS) & (uby[q] <= a.ymax_bits);
+            const float sc = valid ? W_SCALE : 0.f;
+            const int ix = (int)(hx[q] - MAGIC_HI), iy = (int)(hy[q] - MAGIC_HI);
+            wx1[j] = (float)lx[q]; wx0[j] = (float)(~lx[q]);
+            wy1[j] = (float)ly[q] * sc; wy0[j] = (float)(~ly[q]) * sc;
+            off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
+            near_end |= valid & (iy > a.src_h - 3);
+        }
+        if (!__any(near_end)) {
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const pk2 r0 = ld8(simg + off[j]);
+                const pk2 r1 = ld8(simg + off[j] + pitch);
+                a0[j] = r0.a; b0[j] = __builtin_amdgcn_alignbyte(r0.b, r0.a, 3);
+                a1[j] = r1.a; b1[j] = __builtin_amdgcn_alignbyte(r1.b, r1.a, 3);
+            }
+        } else {  // byte-exact loads, +1 taps clamped to the image (their weight is 0 when clamped)
+            const uint32_t last = (uint32_t)a.src_h * pitch - 3u;
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const uint32_t o00 = off[j];
+                const uint32_t o01 = min(o00 + 3u, last), o10 = min(o00 + pitch, last), o11 = min(o00 + pitch + 3u, last);
+                a0[j] = simg[o00] | (simg[o00 + 1] << 8) | (simg[o00 + 2] << 16);
+                b0[j] = simg[o01] | (simg[o01 + 1] << 8) | (simg[o01 + 2] << 16);
+                a1[j] = simg[o10] | (simg[o10 + 1] << 8) | (simg[o10 + 2] << 16);
+                b1[j] = simg[o11] | (simg[o11 + 1] << 8) | (simg[o11 + 2] << 16);
+            }
+        }
+        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 12 * h, store_any & (shift < 4 * h + 4), max(shift - 4 * h, 0));
+    }
 }
 
 // floor(n / d) == umulhi(n, magic) for every n < n_max, or 0 if no such 32-bit magic exists

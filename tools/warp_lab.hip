@@ -73,10 +73,18 @@ int main(int argc, char** argv) {
             a.tiles_x = (G.w + 255) / 256; a.tiles_y = (G.h + 3) / 4; a.nblocks = a.tiles_x * a.tiles_y * B; a.cpx = (a.nblocks + 7) / 8;
             return launch(warp_generic<unsigned char, 3, unsigned char, RWH_BILINEAR>, a, (hipStream_t)0);
         };
+        auto fast = [&](bool px8) {
+            WarpArgs a;
+            a.src = src; a.dst = dst; a.src_img_stride = (long long)src_bytes; a.dst_img_stride = (long long)G.w * G.h * 3;
+            a.src_h = SH; a.src_w = SW; a.bound_h = SH; a.bound_w = SW; a.out_h = G.h; a.out_w = G.w; a.row_begin = 0; a.rows = G.h;
+            return launch_fast(a, ih, G.x0, 1.0, G.y0, 1.0, RWH_U8, B, (hipStream_t)0, px8);
+        };
         struct Case { const char* name; std::function<int()> run; };
         std::vector<Case> cases = {
             {"generic u8 (reference order)", [&] { return call(RWH_BILINEAR, RWH_U8, true); }},
-            {"fast u8", [&] { return call(RWH_BILINEAR, RWH_U8, false); }},
+            {"fast u8 (C ABI default)", [&] { return call(RWH_BILINEAR, RWH_U8, false); }},
+            {"fast u8 px4", [&] { return fast(false); }},
+            {"fast u8 px8", [&] { return fast(true); }},
         };
         const double bytes = (double)B * (src_bytes + (double)G.w * G.h * 3);
         const size_t nbytes = (size_t)G.w * G.h * 3 * B;
