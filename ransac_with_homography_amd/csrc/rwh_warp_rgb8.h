@@ -110,7 +110,19 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][2], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][0], 1, q);
             q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][1], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][2], 3, q);
             w.c = q;
+#if defined(RWH_STORE_NT) || defined(RWH_STORE_SC)
+            {   // tools/warp_lab experiment hook: cache-policy bits on the output store
+                typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+                const u3 dv = {w.a, w.b, w.c};
+#ifdef RWH_STORE_NT
+                asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(drow), "v"(dv) : "memory");
+#else
+                asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" :: "v"(drow), "v"(dv) : "memory");
+#endif
+            }
+#else
             __builtin_memcpy(drow, &w, 12);
+#endif
         } else {
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
@@ -357,6 +369,9 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
 
     // ---- source coordinates of the lane's 4 pixels -----------------------------------------------
+#ifdef RWH_ABL_STORE_SMALL  // tools/warp_lab ablation hook: all stores land in a 200 KB window (stays in L2)
+    drow = reinterpret_cast<DstT*>(dimg + (uint32_t)(lane * 24 + wave * 1536 + (blockIdx.x & 31) * 6144));
+#endif
     const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
     double X[F8_PX], Y[F8_PX], W[F8_PX];
     X[0] = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
@@ -427,7 +442,11 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         // staging lane -> (source row srow of 3, texel group scol of 21): 24 packed bytes in, 8 RGBX texels out
         const int srow = (lane * 49) >> 10;                     // lane / 21 for lane < 64
         const int scol = lane - F8_LANES * srow;
+#ifdef RWH_ABL_LOAD_SMALL   // tools/warp_lab ablation hook: all staging loads come from the first 64 source rows
+        const unsigned char* gbase = simg + (size_t)((uint32_t)(ymn & 63) * pitch + (uint32_t)xmn * 3u);
+#else
         const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+#endif
         const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 24u;
         unsigned char* wlds = my + srow * F8_PITCH + scol * 32;
         const bool mine = (srow < 3) & (8 * scol < ntex);

@@ -295,3 +295,47 @@ def test_stitching_with_injected_matches(gpu, matches):
     out = rs.stitching(f["A"].copy(), f["B"].copy(), blending="Rate", th=4, blendrate=0.2, d=95, k=1500, override=0,
                        matches=matches)
     check_pick(z, "stitch_g5_rate", out, exact=False)
+
+
+def test_config4_panorama_8k_end_to_end(gpu, matches):
+    """BASELINE config 4: foto1A/foto1B upsampled x8 (8192x5464), RANSAC (app.py parameters, threshold
+    scaled with the image) + warp + paste, end to end on one GPU.  Scaling by a power of two is exact
+    in floating point, so the x8 problem must pick the same hypothesis with the same inlier set as the
+    native one, and the canvas geometry must be the native geometry scaled."""
+    import homography as hg
+    import ransac as rs
+    f = load_golden("img_foto1")
+    A8 = np.ascontiguousarray(np.repeat(np.repeat(f["A"], 8, axis=0), 8, axis=1))
+    B8 = np.ascontiguousarray(np.repeat(np.repeat(f["B"], 8, axis=0), 8, axis=1))
+    ptsA, ptsB = matches
+    np.random.seed(0)
+    m1 = rs.HomoModel(th=4, d=95, n=4)
+    H1, inl1, c1 = rs.RANSAC(m1, k=1500).run([ptsA.T, ptsB.T], method="fwd")
+    np.random.seed(0)
+    m8 = rs.HomoModel(th=32, d=95, n=4)
+    r8 = rs.RANSAC(m8, k=1500)
+    H8, inl8, c8 = r8.run([(ptsA * 8).T, (ptsB * 8).T], method="fwd")
+    z = load_golden("g4_ransac_runs")
+    assert int(c1) == int(z["g5_s0_th4_d95_k1500_fwd_count"]) == 114
+    assert abs(int(c8) - int(c1)) <= 2 and r8.last_run["winner"] is not None
+    out = hg.stitchPanorama(B8, A8, H8)
+    native = hg.stitchPanorama(f["B"].copy(), f["A"].copy(), H1)
+    assert abs(out.shape[0] - 8 * native.shape[0]) <= 16 and abs(out.shape[1] - 8 * native.shape[1]) <= 16
+    assert out.dtype == np.uint8 and out.shape[2] == 3
+    # the query image is pasted unchanged; the warped part is non-trivial
+    assert out[:, : B8.shape[1]].any() and out[:, B8.shape[1]:].any()
+
+
+def test_config5_batch_1080p(gpu):
+    """BASELINE config 5 (per-GPU share): a batch of 1080p frames in ONE launch equals frame-by-frame launches."""
+    from ransac_with_homography_amd import kernels
+    g = torch.Generator(device="cpu").manual_seed(7)
+    src = torch.randint(0, 256, (8, 1080, 1920, 3), dtype=torch.uint8, generator=g).to(gpu)
+    inv = np.linalg.inv(H_BENCH)
+    grid = kernels.Grid(0, 1919, 1920, 0, 1079, 1080)
+    full = kernels.warp_backward(src, inv, grid, (1080, 1920), "bilinear", torch.uint8)
+    for b in (0, 3, 7):
+        assert torch.equal(kernels.warp_backward(src[b].contiguous(), inv, grid, (1080, 1920), "bilinear", torch.uint8), full[b])
+    # nearest-neighbour batch path too
+    nn = kernels.warp_backward(src, inv, grid, (1080, 1920), "nn", torch.uint8)
+    assert torch.equal(kernels.warp_backward(src[5].contiguous(), inv, grid, (1080, 1920), "nn", torch.uint8), nn[5])
