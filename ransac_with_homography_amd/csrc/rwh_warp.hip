@@ -198,8 +198,12 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 
 // Fast-path launch (RGB u8, bilinear): returns RWH_E_UNSUPPORTED when the shape needs the generic kernel.
 // px8: 8 pixels per lane (128 x 16 block tiles) instead of 4 (256 x 4).
+// variant: 0 = 4 px per lane (256 x 4 block tiles), 1 = 8 px per lane (128 x 16 block tiles).
+// (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on 128 x 16*group block tiles.)
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
-                int dst_dtype, int batch, hipStream_t s, bool px8) {
+                int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
+                void (*custom)(const FastArgs) = nullptr) {
+    const bool px8 = variant >= 1;
     const int lane_px = px8 ? F8_PX : FP_PX;
     if (w.out_w < lane_px || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
     const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
@@ -219,7 +223,8 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
     a.row_begin = w.row_begin; a.rows = w.rows;
     a.tiles_x = (unsigned)(px8 ? (w.out_w + 127) / 128 : (w.out_w + 255) / 256);
-    a.tiles_y = (unsigned)(px8 ? (w.rows + 15) / 16 : (w.rows + 3) / 4);
+    a.group = variant == 2 ? group : 1;
+    a.tiles_y = (unsigned)(px8 ? (w.rows + 16 * a.group - 1) / (16 * a.group) : (w.rows + 3) / 4);
     const unsigned long long nb = (unsigned long long)a.tiles_x * a.tiles_y * (unsigned)batch;
     if (nb >= (1ull << 31) / 8) return RWH_E_UNSUPPORTED;
     a.nblocks = (unsigned)nb;
@@ -228,7 +233,9 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.tiles_y_magic = div_magic(a.tiles_y, nb / a.tiles_x + 1);
     if ((a.tiles_x > 1 && !a.tiles_x_magic) || (a.tiles_y > 1 && !a.tiles_y_magic)) return RWH_E_UNSUPPORTED;
     const dim3 grid(8u * a.cpx), block(256);
-    if (px8) {
+    if (custom) {
+        hipLaunchKernelGGL(custom, grid, block, 0, s, a);
+    } else if (px8) {
         if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_fast8<unsigned char>, grid, block, 0, s, a);
         else hipLaunchKernelGGL(warp_rgb8_fast8<float>, grid, block, 0, s, a);
     } else {
@@ -289,7 +296,7 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     a.cpx = (a.nblocks + 7u) / 8u;
 
     if (src_dtype == RWH_U8 && channels == 3 && interp == RWH_BILINEAR && (dst_dtype == RWH_U8 || dst_dtype == RWH_F32)) {
-        const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*px8=*/a.out_w >= 128);
+        const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*variant=*/a.out_w >= 128 ? 1 : 0);
         if (st != RWH_E_UNSUPPORTED) return st;  // else: shape outside the fast kernel's limits -> generic kernel
     }
 

@@ -60,6 +60,7 @@ struct FastArgs {
     int row_begin, rows;                                 // produce output rows [row_begin, row_begin+rows)
     unsigned tiles_x, tiles_y, nblocks, cpx;
     unsigned tiles_x_magic, tiles_y_magic;               // floor(n/d) = umulhi(n, magic) for n < nblocks
+    int group;                                           // tools/warp_pipe_experiment.h only: patches per wave
 };
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_as_longlong(v) >> 32); }
@@ -110,7 +111,16 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][2], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][0], 1, q);
             q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][1], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][2], 3, q);
             w.c = q;
-#if defined(RWH_STORE_NT) || defined(RWH_STORE_SC)
+#ifdef RWH_ABL_STORE_X4   // tools/warp_lab ablation hook: same bytes, but as aligned 16-byte stores (scrambled pixels)
+            {
+                const int lane_ = threadIdx.x & 63, pq_ = lane_ & 15;
+                // this half's 12 bytes belong to a 384-byte row segment starting 24*pq_ (+12 for the 2nd half) before drow
+                const bool second = (((size_t)drow / 12) & 1) != 0;   // crude: which half (timing only)
+                unsigned char* seg = reinterpret_cast<unsigned char*>(drow) - (second ? 12 : 0) - 24 * pq_;
+                if (!second && pq_ < 12) { *reinterpret_cast<uint4*>(seg + 32 * pq_) = uint4{w.a, w.b, w.c, w.a}; }
+                if (second && pq_ < 12) { *reinterpret_cast<uint4*>(seg + 32 * pq_ + 16) = uint4{w.a, w.b, w.c, w.b}; }
+            }
+#elif defined(RWH_STORE_NT) || defined(RWH_STORE_SC)
             {   // tools/warp_lab experiment hook: cache-policy bits on the output store
                 typedef uint32_t u3 __attribute__((ext_vector_type(3)));
                 const u3 dv = {w.a, w.b, w.c};
@@ -548,6 +558,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 12 * h, store_any & (shift < 4 * h + 4), max(shift - 4 * h, 0));
     }
 }
+
 
 // floor(n / d) == umulhi(n, magic) for every n < n_max, or 0 if no such 32-bit magic exists
 inline unsigned div_magic(unsigned d, unsigned long long n_max) {

@@ -5,6 +5,7 @@
 // 3840x2160 fixed grid) and reports how many output bytes differ from the generic (reference-order,
 // texel-exact) kernel.
 #include "../ransac_with_homography_amd/csrc/rwh_warp.hip"
+#include "warp_pipe_experiment.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -34,6 +35,16 @@ __global__ void diff_count(const unsigned char* a, const unsigned char* b, size_
     if (d2) atomicAdd(out + 1, d2);
 }
 
+// calibration: plain copies of the same volume (what the memory system delivers with no arithmetic)
+__global__ __launch_bounds__(256) void copy16(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n) {
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n) d[i] = s[i];
+}
+__global__ __launch_bounds__(256) void copy12(const unsigned char* __restrict__ s, unsigned char* __restrict__ d, size_t n12) {
+    size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
+    if (i < n12) { pk3 v; __builtin_memcpy(&v, s + i * 12, 12); __builtin_memcpy(d + i * 12, &v, 12); }
+}
+
 int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16;
     const char* filter = argc > 2 ? argv[2] : nullptr;
@@ -56,6 +67,21 @@ int main(int argc, char** argv) {
     fill_random<<<4096, 256>>>(reinterpret_cast<uint32_t*>(src), src_bytes * B / 4, 1234u);
     CK(hipDeviceSynchronize());
     unsigned long long* d_diff; CK(hipMalloc(&d_diff, 16));
+    hipEvent_t e0s, e1s; CK(hipEventCreate(&e0s)); CK(hipEventCreate(&e1s));
+    {
+        const size_t nbytes = (size_t)2028 * 3771 * 3 * B;   // copy as many bytes as one launch writes (reads the same amount)
+        for (int which = 0; which < 2; ++which) {
+            float best = 1e9f;
+            for (int rep = 0; rep < 5; ++rep) {
+                CK(hipEventRecord(e0s));
+                if (which == 0) copy16<<<(unsigned)((nbytes / 16 + 255) / 256), 256>>>((const uint4*)src, (uint4*)dst, nbytes / 16);
+                else copy12<<<(unsigned)((nbytes / 12 + 255) / 256), 256>>>(src, dst, nbytes / 12);
+                CK(hipEventRecord(e1s)); CK(hipEventSynchronize(e1s));
+                float ms; CK(hipEventElapsedTime(&ms, e0s, e1s)); best = ms < best ? ms : best;
+            }
+            printf("copy %s: %zu MB read + same written: %.3f ms = %.1f GB/s\n", which ? "12 B/lane" : "16 B/lane", nbytes >> 20, best, 2.0 * nbytes / best / 1e6);
+        }
+    }
     struct Geo { int x0, y0, w, h; const char* name; } geo[2] = {{5, 7, 3771, 2028, "auto 3771x2028"}, {0, 0, 3840, 2160, "fixed 3840x2160"}};
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (int g = 0; g < 2; ++g) {
@@ -73,18 +99,22 @@ int main(int argc, char** argv) {
             a.tiles_x = (G.w + 255) / 256; a.tiles_y = (G.h + 3) / 4; a.nblocks = a.tiles_x * a.tiles_y * B; a.cpx = (a.nblocks + 7) / 8;
             return launch(warp_generic<unsigned char, 3, unsigned char, RWH_BILINEAR>, a, (hipStream_t)0);
         };
-        auto fast = [&](bool px8) {
+        auto fast = [&](int variant, int group) {
             WarpArgs a;
             a.src = src; a.dst = dst; a.src_img_stride = (long long)src_bytes; a.dst_img_stride = (long long)G.w * G.h * 3;
             a.src_h = SH; a.src_w = SW; a.bound_h = SH; a.bound_w = SW; a.out_h = G.h; a.out_w = G.w; a.row_begin = 0; a.rows = G.h;
-            return launch_fast(a, ih, G.x0, 1.0, G.y0, 1.0, RWH_U8, B, (hipStream_t)0, px8);
+            return launch_fast(a, ih, G.x0, 1.0, G.y0, 1.0, RWH_U8, B, (hipStream_t)0, variant, group,
+                               variant == 2 ? warp_rgb8_pipe<unsigned char> : nullptr);
         };
         struct Case { const char* name; std::function<int()> run; };
         std::vector<Case> cases = {
             {"generic u8 (reference order)", [&] { return call(RWH_BILINEAR, RWH_U8, true); }},
             {"fast u8 (C ABI default)", [&] { return call(RWH_BILINEAR, RWH_U8, false); }},
-            {"fast u8 px4", [&] { return fast(false); }},
-            {"fast u8 px8", [&] { return fast(true); }},
+            {"fast u8 px4", [&] { return fast(0, 1); }},
+            {"fast u8 px8", [&] { return fast(1, 1); }},
+            {"fast u8 pipe G=4", [&] { return fast(2, 4); }},
+            {"fast u8 pipe G=8", [&] { return fast(2, 8); }},
+            {"fast u8 pipe G=16", [&] { return fast(2, 16); }},
         };
         const double bytes = (double)B * (src_bytes + (double)G.w * G.h * 3);
         const size_t nbytes = (size_t)G.w * G.h * 3 * B;
