@@ -132,13 +132,13 @@ def main():
     idx_dev = torch.from_numpy(idx_table[b:e].astype(np.int32)).to(dev)
     need = kernels.need_count(185, 70, 4)
 
+    ws = kernels.SearchWorkspace(e - b, 185, dev, want_masks=False)
+
     def ransac_step():
-        best = kernels.new_best(dev)
-        Hs, _ = kernels.dlt4_batched(pa, pb, idx_dev)
-        kernels.score_count(Hs, pa, pb, 5.0, "fwd", need, best, hyp_base=b, want_masks=False)
+        kernels.ransac_search(pa, pb, idx_dev, 5.0, "fwd", need, ws, hyp_base=b)   # memset + K1 + K2, one call
         if world > 1:
-            dist.all_reduce(best, op=dist.ReduceOp.MAX)
-        return best.cpu()  # the 16-byte result reaches the host: launch + readback latency included
+            dist.all_reduce(ws.best, op=dist.ReduceOp.MAX)
+        return ws.best.cpu()  # the 16-byte result reaches the host: launch + readback latency included
 
     for _ in range(3):
         ransac_step()
@@ -177,7 +177,7 @@ def main():
                          "read_only_frac": round(B * 3 * SRC_H * SRC_W / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "ransac": {"hyp_per_s": round(K * R / tr, 1), "hypotheses": K, "correspondences": 185,
                        "pair_evals_per_s": round(K * R * 185 / tr, 1), "winner": winner, "winner_count": cnt,
-                       "includes": "K1+K2 launches%s + 16-byte readback per run" % (" + all-reduce(max)" if world > 1 else "")},
+                       "includes": "key reset + K1 + K2%s + 16-byte readback per run" % (" + all-reduce(max)" if world > 1 else "")},
         }
         if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline("%d-frame batch" % B)

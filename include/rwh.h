@@ -139,6 +139,17 @@ RWH_API int rwh_score_count(const float* d_h, const float* d_pts_a, const float*
 RWH_API int rwh_project_points(const float* d_h, const float* d_pts, int m, int inverse,
                        float* d_out, void* stream);
 
+/*
+ * The RANSAC search of ransac.py:176-202 as ONE call: (optional) reset of the two packed keys, then
+ * rwh_dlt4_batched + rwh_score_count on the same stream with caller-provided workspaces (d_h K x 9,
+ * d_flags K, d_counts K, d_masks K x ceil(M/64) or NULL).  Saves two host round trips per run; arguments
+ * as in the two functions above.
+ */
+RWH_API int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k,
+                      double th, int loss, int need, int64_t hyp_base,
+                      float* d_h, uint8_t* d_flags, int32_t* d_counts, uint64_t* d_masks, uint64_t* d_best,
+                      int reset_best, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

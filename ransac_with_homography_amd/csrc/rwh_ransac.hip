@@ -18,6 +18,7 @@
 //      'backward' does the same through inv(val) (float64 inverse rounded to float32).
 // No FMA contraction anywhere (rwh_common.h), no fast-math, IEEE divide / sqrt.
 #include "rwh_common.h"
+#include <cstdlib>
 
 namespace rwh {
 
@@ -192,48 +193,76 @@ __device__ __forceinline__ void inverse3(const float (&hf)[9], float (&inv)[9]) 
         for (int j = 0; j < 3; ++j) inv[3 * i + j] = (float)B[i][j];
 }
 
-template <int LOSS>
+// One wavefront scores HPW consecutive hypotheses.  WORDS > 0: the correspondences (M <= 64*WORDS) live in
+// registers for the whole wave -- lane l holds points l, l+64, ... -- so the loop over hypotheses is pure VALU +
+// scalar loads of H; WORDS == 0: any M, points streamed from L1/L2 per hypothesis.  The wave keeps its best packed
+// key in registers and issues at most one atomic per key word at the end.
+template <int LOSS, int WORDS>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs, const float* __restrict__ pa,
-                                                    const float* __restrict__ pb, int m, int k, double th, int need,
+                                                    const float* __restrict__ pb, int m, int k, int hpw, double th, int need,
                                                     long long hyp_base, int32_t* __restrict__ counts,
                                                     uint64_t* __restrict__ masks, unsigned long long* best,
                                                     float* __restrict__ errs) {
     const int lane = threadIdx.x & 63;
-    const int hyp = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    if (hyp >= k) return;
-    float h[9], hi[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) h[i] = hs[9 * (size_t)hyp + i];
-    if constexpr (LOSS != RWH_LOSS_FWD) inverse3(h, hi);
-
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    const int h_begin = wid * hpw;
+    if (h_begin >= k) return;
+    const int h_end = min(k, h_begin + hpw);
     const int words = (m + 63) >> 6;
-    int count = 0;
-    for (int w = 0; w < words; ++w) {
-        const int j = w * 64 + lane;
-        bool inl = false;
-        if (j < m) {
-            const float2 a = reinterpret_cast<const float2*>(pa)[j];
-            const float2 b = reinterpret_cast<const float2*>(pb)[j];
-            float e;
-            if constexpr (LOSS == RWH_LOSS_FWD) e = proj_err(h, a.x, a.y, b.x, b.y);
-            else if constexpr (LOSS == RWH_LOSS_BACKWARD) e = proj_err(hi, b.x, b.y, a.x, a.y);
-            else { e = proj_err(h, a.x, a.y, b.x, b.y); e = e + proj_err(hi, b.x, b.y, a.x, a.y); }
-            inl = (double)e < th;
-            if (errs) errs[(size_t)hyp * m + j] = e;
+
+    float2 ra[WORDS > 0 ? WORDS : 1], rb[WORDS > 0 ? WORDS : 1];
+    if constexpr (WORDS > 0) {
+#pragma unroll
+        for (int w = 0; w < WORDS; ++w) {
+            const int j = w * 64 + lane;
+            ra[w] = j < m ? reinterpret_cast<const float2*>(pa)[j] : float2{0.f, 0.f};
+            rb[w] = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
         }
-        const unsigned long long bal = __ballot(inl);
-        count += __popcll(bal);
-        if (masks && lane == 0) masks[(size_t)hyp * words + w] = bal;
+    }
+    unsigned long long key0 = 0, key1 = 0;  // wave-local maxima of the two packed words
+    for (int hyp = h_begin; hyp < h_end; ++hyp) {
+        float h[9], hi[9];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) h[i] = hs[9 * (size_t)hyp + i];   // uniform address: scalar loads
+        if constexpr (LOSS != RWH_LOSS_FWD) inverse3(h, hi);
+        int count = 0;
+        auto score = [&](int w, float2 a, float2 b) {
+            const int j = w * 64 + lane;
+            bool inl = false;
+            if (j < m) {
+                float e;
+                if constexpr (LOSS == RWH_LOSS_FWD) e = proj_err(h, a.x, a.y, b.x, b.y);
+                else if constexpr (LOSS == RWH_LOSS_BACKWARD) e = proj_err(hi, b.x, b.y, a.x, a.y);
+                else { e = proj_err(h, a.x, a.y, b.x, b.y); e = e + proj_err(hi, b.x, b.y, a.x, a.y); }
+                inl = (double)e < th;
+                if (errs) errs[(size_t)hyp * m + j] = e;
+            }
+            const unsigned long long bal = __ballot(inl);
+            count += __popcll(bal);
+            if (masks && lane == 0) masks[(size_t)hyp * words + w] = bal;
+        };
+        if constexpr (WORDS > 0) {
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w)
+                if (w < words) score(w, ra[w], rb[w]);
+        } else {
+            for (int w = 0; w < words; ++w) {
+                const int j = w * 64 + lane;
+                const float2 a = j < m ? reinterpret_cast<const float2*>(pa)[j] : float2{0.f, 0.f};
+                const float2 b = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
+                score(w, a, b);
+            }
+        }
+        if (lane == 0) counts[hyp] = count;
+        const unsigned long long inv_idx = 0xFFFFFFFFull - (unsigned long long)(hyp_base + hyp);
+        const unsigned long long key = ((unsigned long long)(unsigned)count << 32) | inv_idx;
+        key0 = key > key0 ? key : key0;
+        if (count >= need) key1 = inv_idx > key1 ? inv_idx : key1;
     }
     if (lane == 0) {
-        counts[hyp] = count;
-        const unsigned long long gidx = (unsigned long long)(hyp_base + hyp);
-        const unsigned long long inv_idx = 0xFFFFFFFFull - gidx;
-        const unsigned long long key = ((unsigned long long)(unsigned)count << 32) | inv_idx;
         // most waves lose against the running best: peek before paying for the atomic
-        if (key > __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[0], key);
-        if (count >= need && inv_idx > __hip_atomic_load(&best[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
-            atomicMax(&best[1], inv_idx);
+        if (key0 > __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[0], key0);
+        if (key1 > __hip_atomic_load(&best[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[1], key1);
     }
 }
 
@@ -274,6 +303,25 @@ extern "C" int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int 
     return check_launch();
 }
 
+namespace rwh {
+template <int LOSS>
+void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
+                  int hpw, double th, int need, long long hyp_base, int32_t* d_counts, uint64_t* d_masks,
+                  unsigned long long* best, float* d_err) {
+    const dim3 block(256);
+#define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, \
+                                        hyp_base, d_counts, d_masks, best, d_err)
+    switch (words <= 4 ? words : 0) {
+        case 1: RWH_SCORE(1); break;
+        case 2: RWH_SCORE(2); break;
+        case 3: RWH_SCORE(3); break;
+        case 4: RWH_SCORE(4); break;
+        default: RWH_SCORE(0); break;
+    }
+#undef RWH_SCORE
+}
+}  // namespace rwh
+
 extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k, double th,
                                int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,
                                uint64_t* d_best, float* d_err, void* stream) {
@@ -283,16 +331,29 @@ extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const flo
     if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ) return RWH_E_INVALID;
     if (k == 0) return RWH_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    const dim3 grid((k + 3) / 4), block(256);
+    // hypotheses per wave: enough waves to fill the chip (>= ~8 per SIMD) before a wave gets more than one
+    int hpw = k / (256 * 4 * 32);   // measured: 1 up to ~30 k hypotheses, 2-4 at 100 k (tools/k2time.py)
+    hpw = hpw < 1 ? 1 : (hpw > 8 ? 8 : hpw);
+    if (const char* e = getenv("RWH_SCORE_HPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) hpw = v; }  // tuning knob
+    const int waves = (k + hpw - 1) / hpw;
+    const dim3 grid((waves + 3) / 4);
+    const int words = (m + 63) / 64;
     unsigned long long* best = reinterpret_cast<unsigned long long*>(d_best);
     if (loss == RWH_LOSS_FWD)
-        hipLaunchKernelGGL(score_kernel<RWH_LOSS_FWD>, grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, th, need,
-                           (long long)hyp_base, d_counts, d_masks, best, d_err);
+        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, (long long)hyp_base, d_counts, d_masks, best, d_err);
     else if (loss == RWH_LOSS_BACKWARD)
-        hipLaunchKernelGGL(score_kernel<RWH_LOSS_BACKWARD>, grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, th, need,
-                           (long long)hyp_base, d_counts, d_masks, best, d_err);
+        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, (long long)hyp_base, d_counts, d_masks, best, d_err);
     else
-        hipLaunchKernelGGL(score_kernel<RWH_LOSS_REPROJ>, grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, th, need,
-                           (long long)hyp_base, d_counts, d_masks, best, d_err);
+        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, (long long)hyp_base, d_counts, d_masks, best, d_err);
     return check_launch();
+}
+
+extern "C" int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k, double th,
+                                 int loss, int need, int64_t hyp_base, float* d_h, uint8_t* d_flags, int32_t* d_counts,
+                                 uint64_t* d_masks, uint64_t* d_best, int reset_best, void* stream) {
+    if (!d_best) return RWH_E_INVALID;
+    if (reset_best && hipMemsetAsync(d_best, 0, 16, static_cast<hipStream_t>(stream)) != hipSuccess) return RWH_E_LAUNCH;
+    const int st = rwh_dlt4_batched(d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags, stream);
+    if (st != RWH_OK) return st;
+    return rwh_score_count(d_h, d_pts_a, d_pts_b, m, k, th, loss, need, hyp_base, d_counts, d_masks, d_best, nullptr, stream);
 }

@@ -111,6 +111,30 @@ def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=Tr
     return counts, masks, err
 
 
+class SearchWorkspace:
+    """Device buffers of one RANSAC search (K hypotheses over M correspondences), reusable across runs."""
+
+    def __init__(self, k, m, device, want_masks=True):
+        self.k, self.m = k, m
+        self.H = torch.empty((k, 9), dtype=torch.float32, device=device)
+        self.flags = torch.empty((k,), dtype=torch.uint8, device=device)
+        self.counts = torch.empty((k,), dtype=torch.int32, device=device)
+        self.masks = torch.empty((k, (m + 63) // 64), dtype=torch.int64, device=device) if want_masks else None
+        self.best = torch.zeros(2, dtype=torch.int64, device=device)
+
+
+def ransac_search(pts_a, pts_b, idx, th, loss, need, ws, hyp_base=0, reset_best=True):
+    """K1 + K2 in one library call (rwh_ransac_search); results land in the workspace `ws`."""
+    lib = _lib.load()
+    _dev_check(pts_a, pts_b, idx)
+    K, M = idx.shape[0], pts_a.shape[0]
+    assert K <= ws.k and M == ws.m and idx.dtype == torch.int32
+    check(lib.rwh_ransac_search(_ptr(pts_a), _ptr(pts_b), M, _ptr(idx), K, float(th), RWH_LOSS[loss], int(need), int(hyp_base),
+                                _ptr(ws.H), _ptr(ws.flags), _ptr(ws.counts), _ptr(ws.masks) if ws.masks is not None else None,
+                                _ptr(ws.best), 1 if reset_best else 0, _lib.stream_ptr()), "rwh_ransac_search")
+    return ws
+
+
 def project_points(h9, pts, inverse):
     """Launch the projection kernel: h9 [9] float32, pts [M,2] float32 -> [3,M] float32."""
     lib = _lib.load()

@@ -163,11 +163,10 @@ class RANSAC(object):
         pa = torch.from_numpy(_points_rows(X)).to(dev)
         pb = torch.from_numpy(_points_rows(Y)).to(dev)
         idx = torch.from_numpy(idx_host.astype(np.int32)).to(dev)
-        best = kernels.new_best(dev)
-        Hs, flags = kernels.dlt4_batched(pa, pb, idx)
-        counts, masks, _ = kernels.score_count(Hs, pa, pb, _weak_threshold(self.th), method,
-                                               kernels.need_count(mx, self.d, self.n), best)
-        winner, _, early = kernels.decode_best(best.cpu().numpy(), k)
+        ws = kernels.SearchWorkspace(k, mx, dev)
+        kernels.ransac_search(pa, pb, idx, _weak_threshold(self.th), method, kernels.need_count(mx, self.d, self.n), ws)
+        Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
+        winner, _, early = kernels.decode_best(ws.best.cpu().numpy(), k)
 
         last_iter = winner if early else k - 1
         if early:  # leave the generator where the reference's `break` would
