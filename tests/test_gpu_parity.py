@@ -339,3 +339,44 @@ def test_config5_batch_1080p(gpu):
     # nearest-neighbour batch path too
     nn = kernels.warp_backward(src, inv, grid, (1080, 1920), "nn", torch.uint8)
     assert torch.equal(kernels.warp_backward(src[5].contiguous(), inv, grid, (1080, 1920), "nn", torch.uint8), nn[5])
+
+
+def _oracle_warp_on_grid(img, inv_h, xs, ys, bound_hw):
+    """numpy float64 restatement of homography.py:166-179 for an arbitrary output grid (the oracle's own
+    interpolator on coordinates computed exactly like the reference computes them)."""
+    from oracle import rwh_oracle as orc
+    xv, yv = np.meshgrid(xs, ys)
+    z = np.dstack([xv, yv, np.ones(xv.shape)]).reshape([xv.size, 3]).T
+    z_t = inv_h @ z
+    z_t /= z_t[-1, :]
+    return orc.bilinear(z_t, img.copy(), bound_hw[0], bound_hw[1], len(ys), len(xs))
+
+
+@pytest.mark.parametrize("case", ["rot30", "zoom_out", "zoom_in", "horizon", "shear"])
+def test_warp_fallback_paths_vs_oracle(gpu, case):
+    """Geometries that leave the LDS-staged fast path: large rotation / zoom-out (footprint does not fit the
+    slab), zoom-in, and a homography whose W changes sign inside the output (per-pixel reciprocal path)."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(99)
+    img = rng.integers(0, 256, (300, 420, 3), dtype=np.uint8)
+    c, s = np.cos(np.pi / 6), np.sin(np.pi / 6)
+    H = {"rot30": np.array([[c, -s, 150.0], [s, c, -40.0], [0, 0, 1.0]]),
+         "zoom_out": np.array([[0.37, 0.0, 3.3], [0.0, 0.41, 2.2], [0, 0, 1.0]]),
+         "zoom_in": np.array([[3.1, 0.0, -20.5], [0.02, 2.7, -11.25], [0, 0, 1.0]]),
+         "horizon": np.array([[1.0, 0.05, 3.0], [0.02, 1.0, 2.0], [2.13e-3, 1.07e-3, 1.0]]),
+         "shear": np.array([[1.0, 0.35, 0.0], [0.21, 1.0, 0.0], [1e-4, 0, 1.0]])}[case]
+    inv = np.linalg.inv(H)
+    if case == "horizon":   # inverse map denominator crosses zero inside this grid (no exactly-zero W: offsets are odd)
+        inv = np.array([[1.0, 0.02, 3.0], [0.01, 1.0, 2.0], [-3.1e-3, -2.3e-3, 1.0]])
+    xs = np.linspace(-13, 506, 520)
+    ys = np.linspace(-7, 352, 360)
+    ref = _oracle_warp_on_grid(img, inv, xs, ys, (300, 420))
+    src = torch.from_numpy(img).to(gpu)
+    grid = kernels.Grid(-13, 506, 520, -7, 352, 360)
+    got = kernels.warp_backward(src, inv, grid, (300, 420), "bilinear", torch.float32).cpu().numpy()
+    ok = close(got, ref)
+    # discontinuity pixels: coordinates within 1e-9 of the mask edge may fall on either side (SURVEY A.5.10)
+    assert (~ok).sum() <= 3, (case, int((~ok).sum()), float(np.abs(got - ref).max()))
+    u8 = kernels.warp_backward(src, inv, grid, (300, 420), "bilinear", torch.uint8).cpu().numpy()
+    d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
+    assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (case, int((d > 1).sum()), float((d != 0).mean()))
