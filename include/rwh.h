@@ -43,6 +43,11 @@ enum { RWH_LOSS_FWD = 0, RWH_LOSS_BACKWARD = 1, RWH_LOSS_REPROJ = 2 };
 #define RWH_WARP_ZERO_ORIGIN 1u /* write zeros into texel (0,0) of every source image first, exactly
                                    like homography.py:112-116 / 126-130 do to the caller's array */
 
+#define RWH_WARP_EXACT 2u       /* reproduce the reference's float64 arithmetic operation by operation (dgemm
+                                   k-order, IEEE divides, separately rounded float64 lerps): results bit-identical to
+                                   numpy's; dst_dtype F64 (bilinear), U8 (bilinear, truncated) or the source dtype
+                                   (nearest).  Several times slower than the default kernels. */
+
 RWH_API int rwh_abi_version(void);
 RWH_API const char* rwh_strerror(int code);
 
@@ -73,7 +78,7 @@ RWH_API const char* rwh_strerror(int code);
  * unit of multi-GPU sharding (output-row tiles or images; no collective).
  *
  * Supported: channels 3 or 4; src_dtype U8 or F32; dst_dtype == src_dtype for
- * RWH_NEAREST; dst_dtype U8 (truncating) or F32 for RWH_BILINEAR.
+ * RWH_NEAREST; dst_dtype U8 (truncating) or F32 for RWH_BILINEAR (F64 or U8 with RWH_WARP_EXACT).
  * n_h is 1 (one homography for the whole batch) or `batch` (inv_h holds batch
  * 3x3 matrices, image b uses the b-th; at most RWH_MAX_H_PER_CALL).
  */

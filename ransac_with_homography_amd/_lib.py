@@ -14,6 +14,7 @@ RWH_U8, RWH_F32, RWH_F64 = 0, 1, 2
 RWH_NEAREST, RWH_BILINEAR = 0, 1
 RWH_LOSS = {"fwd": 0, "backward": 1, "reproj": 2}
 RWH_WARP_ZERO_ORIGIN = 1
+RWH_WARP_EXACT = 2
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR = 1, 2
 
 # every symbol include/rwh.h declares (tests check the library exports them all)

@@ -171,6 +171,113 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
     }
 }
 
+template <typename K> int launch(K kernel, const WarpArgs& a, hipStream_t s);
+
+// ================================================================================================
+// Exact kernel (flag RWH_WARP_EXACT): the reference's float64 arithmetic, operation by operation, so that
+// results are bit-identical to numpy's (fixtures made with numpy 2.2.6 / OpenBLAS 0.3.29):
+//   * grid coordinate = arange*step + start with the endpoint forced to `stop` (numpy.linspace);
+//   * inv(H) @ z in OpenBLAS dgemm k-order: acc = a0*x (rounded), acc = fma(a1, y, acc), acc = acc + a2
+//     (checked against numpy on 23 M elements: 0 mismatches; any other order mismatches 10-30 %);
+//   * z_t /= z_t[2]: IEEE float64 divides;
+//   * bilinear (homography.py:131-137): float mask, astype(int32) truncation, f = z - trunc(z),
+//     p00*(1-fx) + p01*fx, p10*(1-fx) + p11*fx, top*(1-fy) + bot*fy with every product and sum rounded
+//     separately in float64; uint8 output = truncation of that float64 (transformImage's astype(uint8));
+//   * nearest (homography.py:110-121): (z + 0.5) truncated to int32, mask on the integers.
+// ~4x slower than the fast kernel: it exists for parity, not for throughput.
+// ================================================================================================
+template <typename SrcT, int C>
+__device__ __forceinline__ void load_texel_f64(const unsigned char* img, int src_w, int iy, int ix, double (&t)[C]) {
+    const size_t off = ((size_t)iy * (size_t)src_w + (size_t)ix) * (size_t)(C * sizeof(SrcT));
+    if constexpr (sizeof(SrcT) == 1) {
+#pragma unroll
+        for (int c = 0; c < C; ++c) t[c] = (double)img[off + c];
+    } else {
+        const float* p = reinterpret_cast<const float*>(img + off);
+#pragma unroll
+        for (int c = 0; c < C; ++c) t[c] = (double)p[c];
+    }
+}
+
+template <typename SrcT, int C, typename DstT, int INTERP>
+__global__ __launch_bounds__(256) void warp_exact(const WarpArgs a) {
+    unsigned tx, ty, img;
+    if (!decode_tile(a, tx, ty, img)) return;
+    const int lane = threadIdx.x & 63, wrow = threadIdx.x >> 6;
+    const int rr = (int)ty * TILE_ROWS + wrow;
+    if (rr >= a.rows) return;
+    const int r = a.row_begin + rr;
+    const int c0 = ((int)tx * RWH_WAVE + lane) * PX;
+    if (c0 >= a.out_w) return;
+    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;
+    DstT* drow = reinterpret_cast<DstT*>(a.dst + (long long)img * a.dst_img_stride) +
+                 ((size_t)rr * (size_t)a.out_w + (size_t)c0) * C;
+    const double y = grid_coord(r, a.out_h, a.y0, a.step_y, a.y_last);
+    const double bw1 = (double)(a.bound_w - 1), bh1 = (double)(a.bound_h - 1);
+#pragma unroll
+    for (int j = 0; j < PX; ++j) {
+        const int c = c0 + j;
+        if (c >= a.out_w) break;
+        const double x = grid_coord(c, a.out_w, a.x0, a.step_x, a.x_last);
+        const double X = fma(a.ih[1], y, a.ih[0] * x) + a.ih[2];
+        const double Y = fma(a.ih[4], y, a.ih[3] * x) + a.ih[5];
+        const double W = fma(a.ih[7], y, a.ih[6] * x) + a.ih[8];
+        const double sx = X / W, sy = Y / W;
+        if constexpr (INTERP == RWH_NEAREST) {
+            const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
+            const bool valid = (xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1);
+            if (valid) {
+                const size_t off = ((size_t)yi * (size_t)a.src_w + (size_t)xi) * (size_t)(C * sizeof(SrcT));
+                const SrcT* p = reinterpret_cast<const SrcT*>(simg + off);
+#pragma unroll
+                for (int k = 0; k < C; ++k) drow[j * C + k] = (DstT)p[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; ++k) drow[j * C + k] = (DstT)0;
+            }
+        } else {
+            double o[C];
+            const bool valid = (sx >= 0.0) & (sx <= bw1) & (sy >= 0.0) & (sy <= bh1);
+            if (valid) {
+                const int ix = (int)sx, iy = (int)sy;
+                const double fx = sx - (double)ix, fy = sy - (double)iy;
+                const double gx = 1.0 - fx, gy = 1.0 - fy;
+                const int ix1 = min(ix + 1, a.src_w - 1), iy1 = min(iy + 1, a.src_h - 1);
+                double p00[C], p01[C], p10[C], p11[C];
+                load_texel_f64<SrcT, C>(simg, a.src_w, iy, ix, p00);
+                load_texel_f64<SrcT, C>(simg, a.src_w, iy, ix1, p01);
+                load_texel_f64<SrcT, C>(simg, a.src_w, iy1, ix, p10);
+                load_texel_f64<SrcT, C>(simg, a.src_w, iy1, ix1, p11);
+#pragma unroll
+                for (int k = 0; k < C; ++k) {
+                    const double top = p00[k] * gx + p01[k] * fx;   // contraction is off: three roundings, like numpy
+                    const double bot = p10[k] * gx + p11[k] * fx;
+                    o[k] = top * gy + bot * fy;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < C; ++k) o[k] = 0.0;
+            }
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                if constexpr (sizeof(DstT) == 1) drow[j * C + k] = (unsigned char)(int)o[k];
+                else drow[j * C + k] = (DstT)o[k];
+            }
+        }
+    }
+}
+
+template <typename SrcT, int C>
+int dispatch_exact(const WarpArgs& a, int interp, int dst_dtype, hipStream_t s) {
+    if (interp == RWH_NEAREST) {
+        if (dst_dtype != elem<SrcT>::dtype) return RWH_E_UNSUPPORTED;
+        return launch(warp_exact<SrcT, C, SrcT, RWH_NEAREST>, a, s);
+    }
+    if (dst_dtype == RWH_F64) return launch(warp_exact<SrcT, C, double, RWH_BILINEAR>, a, s);
+    if (dst_dtype == RWH_U8) return launch(warp_exact<SrcT, C, unsigned char, RWH_BILINEAR>, a, s);
+    return RWH_E_UNSUPPORTED;
+}
+
 // ---- host side ---------------------------------------------------------------------------------
 template <typename K>
 int launch(K kernel, const WarpArgs& a, hipStream_t s) {
@@ -295,6 +402,11 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     a.nblocks = (unsigned)nb;
     a.cpx = (a.nblocks + 7u) / 8u;
 
+    if (flags & RWH_WARP_EXACT) {
+        if (src_dtype == RWH_U8) return channels == 3 ? dispatch_exact<unsigned char, 3>(a, interp, dst_dtype, s)
+                                                      : dispatch_exact<unsigned char, 4>(a, interp, dst_dtype, s);
+        return channels == 3 ? dispatch_exact<float, 3>(a, interp, dst_dtype, s) : dispatch_exact<float, 4>(a, interp, dst_dtype, s);
+    }
     if (src_dtype == RWH_U8 && channels == 3 && interp == RWH_BILINEAR && (dst_dtype == RWH_U8 || dst_dtype == RWH_F32)) {
         const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*variant=*/a.out_w >= 128 ? 1 : 0);
         if (st != RWH_E_UNSUPPORTED) return st;  // else: shape outside the fast kernel's limits -> generic kernel

@@ -25,9 +25,16 @@ Documented divergences from the reference:
   * `cylindericlMap` / `cylindricalWarp` / `cylindericalTransform` (dead code in
     the reference, needs OpenCV) are not provided beyond an import-compatible stub.
 """
+import os
+
 import numpy as np
 
 from . import _lib, kernels
+
+# EXACT = True (or environment RWH_EXACT=1) routes every warp through the float64 "exact" kernel: bilinear
+# results are then bit-identical to the reference's float64 arrays (and its truncated uint8 images), at a few
+# times the cost of the default float32-blend kernels (which stay within 1e-4 relative / 1 LSB).
+EXACT = os.environ.get("RWH_EXACT", "0") == "1"
 
 __all__ = [
     "calc_corresp", "calc_correspLinear", "calc_correspCollective", "calc_correspLinearCollective",
@@ -164,16 +171,18 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
     src, was_numpy, np_dtype = _to_device(img)
     if convert == "nn":
         out_dtype = src.dtype
+    elif EXACT:
+        out_dtype = torch.uint8 if u8_out else torch.float64
     else:
         out_dtype = torch.uint8 if u8_out else torch.float32
-    out = kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=True)
+    out = kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=True, exact=EXACT)
     if not was_numpy:
         return out
     _blank_origin(img)
     res = out.cpu().numpy()
     if convert == "nn":
         return res if res.dtype == np_dtype else res.astype(np_dtype)
-    return res if u8_out else res.astype(np.float64)  # the reference's bilinear yields float64
+    return res if (u8_out or res.dtype == np.float64) else res.astype(np.float64)  # the reference's bilinear yields float64
 
 
 def _bounds(h, w, H, boundary):

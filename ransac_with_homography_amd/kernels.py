@@ -11,9 +11,9 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (RWH_BILINEAR, RWH_F32, RWH_LOSS, RWH_NEAREST, RWH_U8, RWH_WARP_ZERO_ORIGIN, check)
+from ._lib import (RWH_BILINEAR, RWH_F32, RWH_F64, RWH_LOSS, RWH_NEAREST, RWH_U8, RWH_WARP_EXACT, RWH_WARP_ZERO_ORIGIN, check)
 
-_DTYPE = {torch.uint8: RWH_U8, torch.float32: RWH_F32}
+_DTYPE = {torch.uint8: RWH_U8, torch.float32: RWH_F32, torch.float64: RWH_F64}
 INTERP = {"nn": RWH_NEAREST, "bilinear": RWH_BILINEAR}
 
 
@@ -46,10 +46,11 @@ class Grid:
             self.y_last = self.y0
 
 
-def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=True, rows=None, out=None):
+def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=True, rows=None, out=None, exact=False):
     """Launch K3.  `src`: [B,H,W,C] or [H,W,C] uint8/float32 GPU tensor.
     Returns a tensor [B,rows,out_w,C] (or without B) of `out_dtype` holding
-    output rows `rows=(begin,end)` (default: all)."""
+    output rows `rows=(begin,end)` (default: all).  `exact=True` selects the float64 kernel that
+    reproduces the reference's arithmetic bit for bit (out_dtype float64 / uint8 for bilinear)."""
     lib = _lib.load()
     _dev_check(src)
     squeeze = src.dim() == 3
@@ -71,7 +72,7 @@ def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=Tru
         grid.x0, grid.step_x, grid.x_last, grid.y0, grid.step_y, grid.y_last,
         grid.out_h, grid.out_w, int(bound_hw[0]), int(bound_hw[1]), INTERP[interp],
         _ptr(out), _DTYPE[out_dtype], (r1 - r0) * grid.out_w * C * out.element_size(),
-        r0, r1, RWH_WARP_ZERO_ORIGIN if zero_origin else 0, _lib.stream_ptr())
+        r0, r1, (RWH_WARP_ZERO_ORIGIN if zero_origin else 0) | (RWH_WARP_EXACT if exact else 0), _lib.stream_ptr())
     check(st, "rwh_warp_backward")
     return out[0] if squeeze else out
 

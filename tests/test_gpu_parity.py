@@ -380,3 +380,66 @@ def test_warp_fallback_paths_vs_oracle(gpu, case):
     u8 = kernels.warp_backward(src, inv, grid, (300, 420), "bilinear", torch.uint8).cpu().numpy()
     d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
     assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (case, int((d > 1).sum()), float((d != 0).mean()))
+
+
+# ------------------------------------------------------------------------------------------------
+# Exact mode (RWH_WARP_EXACT): bit-identical float64 / uint8 results
+# ------------------------------------------------------------------------------------------------
+@pytest.fixture
+def exact_mode():
+    import ransac_with_homography_amd.homography as impl
+    old = impl.EXACT
+    impl.EXACT = True
+    yield impl
+    impl.EXACT = old
+
+
+def _sha(a):
+    import hashlib
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def test_exact_mode_small_goldens_bit_identical(gpu, exact_mode):
+    """Every G6 output of the reference -- float64 bilinear, uint8 transformImageH, scan mode, boundary=1, RGBA
+    float32 -- reproduced bit for bit (np.array_equal on float64)."""
+    import homography as hg
+    z = load_golden("g6_small_warps")
+    for iname in ("noise", "ramp"):
+        img = z["img_" + iname]
+        for hn in [str(h) for h in z["H_names"]]:
+            H = z["H_" + hn]
+            o, mx, my = hg.wrapPerspective(img.copy(), H, convert="bilinear")
+            k = "wp_%s_%s_bilinear" % (iname, hn)
+            assert o.dtype == np.float64 and np.array_equal(o, z[k]), k
+            o, _, _ = hg.wrapPerspective(img.copy(), H, convert="nn")
+            assert np.array_equal(o, z["wp_%s_%s_nn" % (iname, hn)])
+            o, _, _ = hg.transformImageH(img.copy(), H)
+            assert o.dtype == np.uint8 and np.array_equal(o, z["tih_%s_%s" % (iname, hn)])
+        o, _, _ = hg.wrapPerspective(img.copy(), z["H_rot"], convert="bilinear", boundary=1)
+        assert np.array_equal(o, z["wpb_%s_rot_bilinear" % iname])
+        hs, ws, _ = img.shape
+        for hn in ("bench", "rot"):
+            o, _, _ = hg.wrapPerspectiveScan(img.copy(), z["H_" + hn], (hs - 8, ws - 16), convert="bilinear")
+            assert np.array_equal(o, z["scan_%s_%s_bilinear" % (iname, hn)])
+        rgba = z["rgba_" + iname]
+        o, _, _ = hg.wrapPerspective(rgba.copy(), z["H_notebook"], convert="bilinear")
+        assert o.dtype == np.float64 and np.array_equal(o, z["wp4_%s_notebook_bilinear" % iname])
+
+
+def test_exact_mode_photo_goldens_sha256(gpu, exact_mode):
+    """G7 / G8: the SHA-256 of the full float64 warp of notebook.jpg (1607 x 1251 x 3), of the uint8 scanner / crop
+    outputs and of the stitched canvases equals the reference's."""
+    import homography as hg
+    z = load_golden("g7_notebook")
+    img = load_golden("img_notebook")["img"]
+    o, mx, my = hg.wrapPerspective(img.copy(), z["H"], convert="bilinear")
+    assert _sha(o) == str(z["wp_bilinear_sha256"])
+    assert _sha(hg.transformImage(img.copy(), z["u"], z["v"])) == str(z["ti_sha256"])
+    assert _sha(hg.transformImage(img.copy(), z["u"], z["v_a4"], box=[1188, 840])) == str(z["scan_a4_sha256"])
+    z = load_golden("g8_stitch")
+    f = load_golden("img_foto1")
+    o, _, _ = hg.transformImageH(f["A"].copy(), z["H_notebook"])
+    assert _sha(o) == str(z["tih_sha256"])
+    assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"])) == str(z["stitch_paste_sha256"])
+    assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"], blending="Rate", blendrate=0.2)) == str(z["stitch_rate_sha256"])
+    assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_g5"], blending="Rate", blendrate=0.2)) == str(z["stitch_g5_rate_sha256"])
