@@ -19,9 +19,10 @@ Documented divergences from the reference:
     (coordinate exactly on the last column/row; its weight is 0 there);
   * scan-mode bounds larger than the source are clipped to the source (the
     reference raises IndexError or reads wrapped rows);
-  * the bilinear blend is float32 on float64-derived weights (<= 1e-4 relative to
-    the reference's float64 blend, typically 3e-7); uint8 results can therefore
-    differ by 1 LSB where the float64 value sits within ~1e-5 of an integer;
+  * with the fast kernels (torch tensors in, or EXACT = False) the bilinear blend is float32 on
+    float64-derived weights (<= 1e-4 relative to the reference's float64 blend, typically 3e-7) and
+    uint8 results can differ by 1 LSB where the float64 value sits within ~1e-5 of an integer; with the
+    exact kernel (numpy arrays in, the default) results are bit-identical to the reference's;
   * `cylindericlMap` / `cylindricalWarp` / `cylindericalTransform` (dead code in
     the reference, needs OpenCV) are not provided beyond an import-compatible stub.
 """
@@ -31,10 +32,13 @@ import numpy as np
 
 from . import _lib, kernels
 
-# EXACT = True (or environment RWH_EXACT=1) routes every warp through the float64 "exact" kernel: bilinear
-# results are then bit-identical to the reference's float64 arrays (and its truncated uint8 images), at a few
-# times the cost of the default float32-blend kernels (which stay within 1e-4 relative / 1 LSB).
-EXACT = os.environ.get("RWH_EXACT", "0") == "1"
+# Which warp kernels serve this module:
+#   EXACT = None (default)  numpy arrays in  -> the float64 "exact" kernel: results bit-identical to the reference's
+#                                               float64 arrays and truncated uint8 images (a host round trip dominates
+#                                               the call anyway);
+#                           torch tensors in -> the fast float32-blend kernels (<= 1e-4 relative, uint8 within 1 LSB);
+#   EXACT = True / False    force one or the other (environment: RWH_EXACT=1 / RWH_EXACT=0).
+EXACT = {"1": True, "0": False}.get(os.environ.get("RWH_EXACT", ""), None)
 
 __all__ = [
     "calc_corresp", "calc_correspLinear", "calc_correspCollective", "calc_correspLinearCollective",
@@ -169,13 +173,14 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
         raise KeyError(convert)  # convertfunc[convert], homography.py:179 / 208
     inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))  # homography.py:172 / 203 (raises LinAlgError)
     src, was_numpy, np_dtype = _to_device(img)
+    exact = was_numpy if EXACT is None else bool(EXACT)
     if convert == "nn":
         out_dtype = src.dtype
-    elif EXACT:
+    elif exact:
         out_dtype = torch.uint8 if u8_out else torch.float64
     else:
         out_dtype = torch.uint8 if u8_out else torch.float32
-    out = kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=True, exact=EXACT)
+    out = kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=True, exact=exact)
     if not was_numpy:
         return out
     _blank_origin(img)

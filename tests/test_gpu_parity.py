@@ -25,6 +25,17 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 
+@pytest.fixture(autouse=True)
+def fast_kernels_by_default():
+    """The numpy-facing API defaults to the exact float64 kernel; the tolerance tests below are about the FAST
+    kernels, so they force them.  Tests of the exact / default behaviour override this with `exact_mode` / `auto_mode`."""
+    import ransac_with_homography_amd.homography as impl
+    old = impl.EXACT
+    impl.EXACT = False
+    yield
+    impl.EXACT = old
+
+
 @pytest.fixture(scope="module")
 def gpu():
     from ransac_with_homography_amd import _lib
@@ -392,6 +403,26 @@ def exact_mode():
     impl.EXACT = True
     yield impl
     impl.EXACT = old
+
+
+@pytest.fixture
+def auto_mode():
+    import ransac_with_homography_amd.homography as impl
+    old = impl.EXACT
+    impl.EXACT = None
+    yield impl
+    impl.EXACT = old
+
+
+def test_default_mode_numpy_exact_tensor_fast(gpu, auto_mode):
+    """Default policy: numpy in -> bit-identical to the reference; torch tensor in -> fast kernels (float32 out)."""
+    import homography as hg
+    z = load_golden("g6_small_warps")
+    img, H = z["img_noise"], z["H_bench"]
+    o, _, _ = hg.wrapPerspective(img.copy(), H, convert="bilinear")
+    assert np.array_equal(o, z["wp_noise_bench_bilinear"])
+    t, _, _ = hg.wrapPerspective(torch.from_numpy(img.copy()).to(gpu), H, convert="bilinear")
+    assert t.is_cuda and t.dtype == torch.float32 and close(t.cpu().numpy(), z["wp_noise_bench_bilinear"]).all()
 
 
 def _sha(a):
