@@ -155,6 +155,21 @@ RWH_API int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m,
                       float* d_h, uint8_t* d_flags, int32_t* d_counts, uint64_t* d_masks, uint64_t* d_best,
                       int reset_best, void* stream);
 
+/*
+ * Fused panorama compositor.  Replaces the body of stitchPanorama (homography.py:288-338) after its canvas
+ * geometry (host, homography.py:303-321): addAlpha('Rate') + transformImageH + paste / alpha blend, in one pass
+ * over the canvas, float64 arithmetic in the reference's order -> uint8 canvas bit-identical to the reference's.
+ * d_img_t: imgT (t_h x t_w x 3 uint8, the image warped by H); d_img_q: imgQ (q_h x q_w x 3 uint8).
+ * inv_h: inv(H); (grid_x0, grid_y0, warp_w, warp_h): wrapPerspective's output grid (min_x, min_y, max_w, max_h);
+ * (tsx, tsy) / (qsx, qsy): where the warped imgT / imgQ sit on the canvas_h x canvas_w canvas.
+ * blend == 0: paste imgQ over the warped imgT; blend != 0: the 'Rate' alpha blend with blendrate `rate`.
+ * flags: RWH_WARP_ZERO_ORIGIN blanks texel (0,0) of imgT first, as bilinear() does to the caller's array.
+ */
+RWH_API int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const void* d_img_q, int q_h, int q_w,
+                        const double* inv_h, int grid_x0, int grid_y0, int warp_w, int warp_h,
+                        int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
+                        int blend, double rate, void* d_canvas, unsigned flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

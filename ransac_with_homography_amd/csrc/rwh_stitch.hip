@@ -1,0 +1,127 @@
+// Fused panorama compositor: replaces, in ONE pass over the canvas,
+//   addAlpha(imgT, 'Rate', rate)                                 homography.py:250-258
+//   transformImageH(imgT[, alpha]) -> wrapPerspective + bilinear  homography.py:230-242, 142-184, 123-138
+//   the canvas paste / alpha blend of stitchPanorama             homography.py:322-338
+// Nothing is materialised: no H x W x 4 float32 alpha image, no float64 warped RGBA, no float32 canvas.
+// Every canvas pixel evaluates the reference's float64 arithmetic in the reference's order (the warp part is
+// warp_exact's recipe, rwh_warp.hip), so the uint8 canvas is bit-identical to stitchPanorama's.
+#include "rwh_common.h"
+
+namespace rwh {
+
+struct StitchArgs {
+    const unsigned char* src_t;   // imgT, ht_src x wt_src x 3 uint8 (texel (0,0) already blanked)
+    const unsigned char* src_q;   // imgQ, hq x wq x 3 uint8
+    unsigned char* dst;           // canvas fh x fw x 3 uint8
+    double ih[9];                 // inv(H)
+    int t_h, t_w;                 // imgT size
+    int q_h, q_w;                 // imgQ size
+    int fh, fw;                   // canvas size
+    int tsx, tsy, wt, ht;         // warped-T rectangle on the canvas and its size (= the warp's output grid)
+    int gx0, gy0;                 // warp grid origin (min_x, min_y): output pixel (c, r) of the warp is at (gx0 + c, gy0 + r)
+    int qsx, qsy;                 // imgQ rectangle origin on the canvas
+    int blend;                    // 0 = paste (imgQ over warped imgT), 1 = alpha blend
+    float alpha_t;                // float32(rate + 1e-10): alpha plane of imgT
+    float alpha_q_in, alpha_q_out;  // canvas alpha inside / outside the imgQ rectangle (float32)
+};
+
+__device__ __forceinline__ double u8(const unsigned char* p) { return (double)*p; }
+
+__global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
+    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cx >= a.fw || cy >= a.fh) return;
+    unsigned char* out = a.dst + ((size_t)cy * a.fw + cx) * 3;
+
+    const int qx = cx - a.qsx, qy = cy - a.qsy;
+    const bool in_q = (qx >= 0) & (qx < a.q_w) & (qy >= 0) & (qy < a.q_h);
+    const unsigned char* q = a.src_q + ((size_t)(in_q ? qy : 0) * a.q_w + (in_q ? qx : 0)) * 3;
+    const int tx = cx - a.tsx, ty = cy - a.tsy;
+    const bool in_t = (tx >= 0) & (tx < a.wt) & (ty >= 0) & (ty < a.ht);
+
+    if (!a.blend && in_q) {          // paste: imgQ is written last (homography.py:337-338)
+        out[0] = q[0]; out[1] = q[1]; out[2] = q[2];
+        return;
+    }
+    double t_rgb[3] = {0.0, 0.0, 0.0}, t_a = 0.0;
+    if (in_t) {
+        // warp_exact's coordinate recipe: dgemm k-order, IEEE divides
+        const double x = (double)(a.gx0 + tx), y = (double)(a.gy0 + ty);
+        const double X = fma(a.ih[1], y, a.ih[0] * x) + a.ih[2];
+        const double Y = fma(a.ih[4], y, a.ih[3] * x) + a.ih[5];
+        const double W = fma(a.ih[7], y, a.ih[6] * x) + a.ih[8];
+        const double sx = X / W, sy = Y / W;
+        const bool valid = (sx >= 0.0) & (sx <= (double)(a.t_w - 1)) & (sy >= 0.0) & (sy <= (double)(a.t_h - 1));
+        if (valid) {
+            const int ix = (int)sx, iy = (int)sy;
+            const double fx = sx - (double)ix, fy = sy - (double)iy;
+            const double gx = 1.0 - fx, gy = 1.0 - fy;
+            const int ix1 = min(ix + 1, a.t_w - 1), iy1 = min(iy + 1, a.t_h - 1);
+            const unsigned char* p00 = a.src_t + ((size_t)iy * a.t_w + ix) * 3;
+            const unsigned char* p01 = a.src_t + ((size_t)iy * a.t_w + ix1) * 3;
+            const unsigned char* p10 = a.src_t + ((size_t)iy1 * a.t_w + ix) * 3;
+            const unsigned char* p11 = a.src_t + ((size_t)iy1 * a.t_w + ix1) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const double top = u8(p00 + k) * gx + u8(p01 + k) * fx;
+                const double bot = u8(p10 + k) * gx + u8(p11 + k) * fx;
+                t_rgb[k] = top * gy + bot * fy;
+            }
+            if (a.blend) {   // the alpha plane is constant except texel (0,0), which bilinear() blanks
+                const double A = (double)a.alpha_t;
+                const double a00 = (ix | iy) == 0 ? 0.0 : A, a01 = (ix1 | iy) == 0 ? 0.0 : A;
+                const double a10 = (ix | iy1) == 0 ? 0.0 : A, a11 = (ix1 | iy1) == 0 ? 0.0 : A;
+                const double top = a00 * gx + a01 * fx, bot = a10 * gx + a11 * fx;
+                t_a = top * gy + bot * fy;
+            }
+        }
+    }
+    if (!a.blend) {                  // paste, outside imgQ: truncated warp (transformImageH's astype(uint8)) or 0
+#pragma unroll
+        for (int k = 0; k < 3; ++k) out[k] = (unsigned char)(int)t_rgb[k];
+        return;
+    }
+    // float32 canvas: rgb = imgQ (or 0), alpha = alpha_q_in / alpha_q_out; blended inside the warped rectangle
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const float cq = in_q ? (float)q[k] : 0.f;
+        float v = cq;
+        if (in_t) {
+            const double qa = (double)(in_q ? a.alpha_q_in : a.alpha_q_out);
+            const double base = qa + t_a;
+            const double r = (qa / base) * (double)cq + (t_a / base) * t_rgb[k];
+            v = (float)r;            // assignment into the float32 canvas
+        }
+        out[k] = (unsigned char)(int)v;
+    }
+}
+
+}  // namespace rwh
+
+extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const void* d_img_q, int q_h, int q_w,
+                                   const double* inv_h, int grid_x0, int grid_y0, int warp_w, int warp_h,
+                                   int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
+                                   int blend, double rate, void* d_canvas, unsigned flags, void* stream) {
+    using namespace rwh;
+    if (!d_img_t || !d_img_q || !d_canvas || !inv_h) return RWH_E_INVALID;
+    if (t_h < 2 || t_w < 2 || q_h <= 0 || q_w <= 0 || warp_w <= 0 || warp_h <= 0 || canvas_h <= 0 || canvas_w <= 0) return RWH_E_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (flags & RWH_WARP_ZERO_ORIGIN) {
+        if (hipMemsetAsync(const_cast<void*>(d_img_t), 0, 3, s) != hipSuccess) return RWH_E_LAUNCH;
+    }
+    StitchArgs a;
+    a.src_t = static_cast<const unsigned char*>(d_img_t);
+    a.src_q = static_cast<const unsigned char*>(d_img_q);
+    a.dst = static_cast<unsigned char*>(d_canvas);
+    for (int i = 0; i < 9; ++i) a.ih[i] = inv_h[i];
+    a.t_h = t_h; a.t_w = t_w; a.q_h = q_h; a.q_w = q_w; a.fh = canvas_h; a.fw = canvas_w;
+    a.tsx = tsx; a.tsy = tsy; a.wt = warp_w; a.ht = warp_h; a.gx0 = grid_x0; a.gy0 = grid_y0; a.qsx = qsx; a.qsy = qsy;
+    a.blend = blend ? 1 : 0;
+    // the reference's Python-float arithmetic, then the float32 storage of its arrays
+    a.alpha_t = (float)(rate + 1e-10);                 // addAlpha: rate += 1e-10; imgn[:, :, c] = rate   (float32 array)
+    a.alpha_q_in = (float)(1 + 1e-10 - rate);          // imgn[q-rect, 3] = 1 + 1e-10 - blendrate            (float32 array)
+    a.alpha_q_out = (float)1e-10;                      // imgn[:, :, 3] += 1e-10 on a float32 zero
+    const dim3 grid((canvas_w + 63) / 64, (canvas_h + 3) / 4), block(256);
+    hipLaunchKernelGGL(stitch_kernel, grid, block, 0, s, a);
+    return check_launch();
+}

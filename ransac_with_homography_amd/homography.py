@@ -340,10 +340,9 @@ def _stitch_geometry(wt, ht, wq, hq, mx, my):
     return (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (max(tex + 1, qex + 1), max(tey + 1, qey + 1))
 
 
-def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0.2):
-    """Warp imgT by H on the GPU and composite it with imgQ (homography.py:288-338).
-    `method` is ignored exactly as in the reference (always bilinear).  The compositor is
-    elementwise host numpy for now (SURVEY.md 8f row f-1 lists its fusion as a next step)."""
+def _stitch_host(imgQ, imgT, H, blending, blendrate):
+    """stitchPanorama with the compositor on the host (homography.py:296-338 verbatim in structure): used for the
+    blending modes the fused kernel does not cover (anything truthy other than 'Rate') and for non-uint8 images."""
     if blending:
         imgT = addAlpha(imgT, method=blending, rate=blendrate)
     img_t, mx, my = transformImageH(imgT, H)
@@ -366,6 +365,50 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     imgn[tsy:tey + 1, tsx:tex + 1, :] = img_t
     imgn[qsy:qey + 1, qsx:qex + 1, :] = imgQ
     return imgn
+
+
+def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0.2):
+    """Warp imgT by H and composite it with imgQ on a common canvas (homography.py:288-338).  `method` is ignored
+    exactly as in the reference (always bilinear).
+
+    uint8 RGB images with blending False or 'Rate' run in ONE fused kernel (`rwh_stitch_panorama`): alpha plane,
+    warp, paste / alpha blend per canvas pixel in the reference's float64 arithmetic -- the canvas is bit-identical
+    to the reference's and nothing intermediate (RGBA float32 image, float64 warp, float32 canvas) is materialised."""
+    import torch
+    fused = (blending is False or blending is None or blending == 0 or blending == 'Rate')
+    tens = _is_tensor(imgQ) or _is_tensor(imgT)
+    if not tens:
+        fused = fused and np.asarray(imgQ).dtype == np.uint8 and np.asarray(imgT).dtype == np.uint8
+    else:
+        fused = fused and imgQ.dtype == torch.uint8 and imgT.dtype == torch.uint8
+    fused = fused and imgQ.shape[2] == 3 and imgT.shape[2] == 3
+    if not fused:
+        return _stitch_host(imgQ, imgT, H, blending, blendrate)
+    if blending:
+        print(blendrate + 1e-10)   # addAlpha prints the rate it stores (homography.py:257)
+    h, w, _ = imgT.shape
+    mx, my, wt, ht = _bounds(h, w, H, 0)
+    if wt <= 0 or ht <= 0:
+        raise ValueError("Number of samples, %d, must be non-negative." % min(wt, ht))
+    hq, wq, _ = imgQ.shape
+    (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (fw, fh) = _stitch_geometry(wt, ht, wq, hq, mx, my)
+    inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))
+    dev = _lib.require_gpu()
+    if tens:
+        t_dev = imgT.to(dev).contiguous()
+        q_dev = imgQ.to(dev).contiguous()
+        if blending:
+            t_dev = t_dev.clone()      # addAlpha copies: the caller's imgT keeps its texel (0,0)
+    else:
+        t_dev = torch.from_numpy(np.ascontiguousarray(imgT)).to(dev)
+        q_dev = torch.from_numpy(np.ascontiguousarray(imgQ)).to(dev)
+    out = kernels.stitch_panorama(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), (fh, fw),
+                                  bool(blending), blendrate, zero_origin=True)
+    if tens:
+        return out
+    if not blending:
+        _blank_origin(imgT)            # transformImageH -> bilinear blanks the caller's texel (0,0) in the paste path
+    return out.cpu().numpy()
 
 
 def cylindericlMap(img, f=1600):

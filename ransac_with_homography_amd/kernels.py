@@ -147,6 +147,22 @@ def project_points(h9, pts, inverse):
     return out
 
 
+def stitch_panorama(img_t, img_q, inv_h, grid_origin, warp_wh, t_origin, q_origin, canvas_hw, blend, rate, zero_origin=True):
+    """Launch the fused compositor: img_t / img_q [H,W,3] uint8 GPU tensors -> canvas [fh,fw,3] uint8."""
+    lib = _lib.load()
+    _dev_check(img_t, img_q)
+    assert img_t.dtype == torch.uint8 and img_q.dtype == torch.uint8 and img_t.shape[2] == 3 and img_q.shape[2] == 3
+    fh, fw = canvas_hw
+    out = torch.empty((fh, fw, 3), dtype=torch.uint8, device=img_t.device)
+    ih = np.ascontiguousarray(inv_h, dtype=np.float64).reshape(9)
+    check(lib.rwh_stitch_panorama(_ptr(img_t), img_t.shape[0], img_t.shape[1], _ptr(img_q), img_q.shape[0], img_q.shape[1],
+                                  ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(grid_origin[0]), int(grid_origin[1]),
+                                  int(warp_wh[0]), int(warp_wh[1]), int(t_origin[0]), int(t_origin[1]), int(q_origin[0]),
+                                  int(q_origin[1]), int(fh), int(fw), 1 if blend else 0, float(rate), _ptr(out),
+                                  RWH_WARP_ZERO_ORIGIN if zero_origin else 0, _lib.stream_ptr()), "rwh_stitch_panorama")
+    return out
+
+
 def decode_best(best_words, k_total):
     """Unpack the two argmax words (host ints) -> (winner_index, count, early_exit).
     Word 1 (first index reaching `need`) takes precedence, like the reference's
