@@ -53,8 +53,8 @@ def cpu_baseline(frames_note):
     orc.ransac_table(X, Y, idx, th=5, method="fwd")
     tr = time.perf_counter() - t0
     return {"value": round(mpix / t, 3), "unit": "Mpix/s", "cores": 1, "kind": "port",
-            "sample": "1 frame 3840x2160 RGB u8 -> %dx%d (of the %s), numpy oracle, min of 2 after warm-up; "
-                      "os.cpu_count=%d OPENBLAS_NUM_THREADS=%s" % (out.shape[0], out.shape[1], frames_note,
+            "sample": "1 frame %dx%d RGB u8 -> %dx%d (of the %s), numpy oracle, min of 2 after warm-up; "
+                      "os.cpu_count=%d OPENBLAS_NUM_THREADS=%s" % (SRC_W, SRC_H, out.shape[0], out.shape[1], frames_note,
                                                                    os.cpu_count(), os.environ.get("OPENBLAS_NUM_THREADS", "unset")),
             "ransac_hyp_per_s": round(300 / tr, 1), "ransac_sample": "300 hypotheses x 185 correspondences, fwd"}
 
@@ -65,8 +65,11 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=32, help="4K frames per step (per GPU)")
+    ap.add_argument("--src", default="3840x2160", help="source frame WxH (default: the BASELINE 4K configuration)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     args = ap.parse_args()
+    global SRC_H, SRC_W
+    SRC_W, SRC_H = (int(v) for v in args.src.lower().split("x"))
 
     import torch
     import torch.distributed as dist
@@ -178,15 +181,15 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tpath):
-            t32 = json.load(open(tpath)).get("warp_rgb8_bilinear_u8_bytes_per_launch")   # measured at 32 frames per launch
-            traffic = int(t32 * B / 32) if t32 else None
+            t32 = json.load(open(tpath)).get("warp_rgb8_bilinear_u8_bytes_per_launch")   # measured: 32 4K frames per launch
+            traffic = int(t32 * B / 32) if (t32 and (SRC_W, SRC_H) == (3840, 2160)) else None
         line = {
             "metric": "backward-warp Mpixels/sec (+ RANSAC hypotheses/sec)", "value": round(value, 1), "unit": "Mpix/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8 (f64 coordinates, f32 blend)", "data": "synthetic",
-            "config": {"workload": "transformImageH warp 3840x2160 RGB u8 bilinear -> %dx%d u8, %d distinct frames per "
-                                   "GPU per step, Hs mild perspective" % (out_h, out_w, B),
+            "config": {"workload": "transformImageH warp %dx%d RGB u8 bilinear -> %dx%d u8, %d distinct frames per "
+                                   "GPU per step, Hs mild perspective" % (SRC_W, SRC_H, out_h, out_w, B),
                        "frames_per_step_per_gpu": B, "sharding": "by image, no collective"},
             "roofline": {"bound": "hbm", "kernel": "warp_rgb8_fast<u8>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),

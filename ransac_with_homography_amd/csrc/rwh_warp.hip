@@ -74,7 +74,7 @@ __device__ __forceinline__ float ub(uint32_t v, int byte) { return (float)((v >>
 
 // ---- texel access for the generic path ---------------------------------------------------------
 template <typename SrcT, int C>
-__device__ __forceinline__ void load_texel(const unsigned char* img, int src_w, int iy, int ix, float (&t)[C]) {
+__device__ __forceinline__ void load_texel(const unsigned char* img, size_t img_bytes, int src_w, int iy, int ix, float (&t)[C]) {
     const size_t off = ((size_t)iy * (size_t)src_w + (size_t)ix) * (size_t)(C * sizeof(SrcT));
     if constexpr (sizeof(SrcT) == 1) {
         if constexpr (C == 4) {
@@ -82,8 +82,15 @@ __device__ __forceinline__ void load_texel(const unsigned char* img, int src_w, 
 #pragma unroll
             for (int c = 0; c < 4; ++c) t[c] = ub(v, c);
         } else {
+            // RGB: one unaligned 4-byte load (3 bytes used) unless that would step past the last texel of the image
+            if (off + 4 <= img_bytes) {
+                const uint32_t v = ld4(img + off);
 #pragma unroll
-            for (int c = 0; c < C; ++c) t[c] = (float)img[off + c];
+                for (int c = 0; c < C; ++c) t[c] = ub(v, c);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C; ++c) t[c] = (float)img[off + c];
+            }
         }
     } else {
         const float* p = reinterpret_cast<const float*>(img + off);
@@ -114,6 +121,7 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
     if (c0 >= a.out_w) return;
 
     const unsigned char* simg = a.src + (long long)img * a.src_img_stride;
+    const size_t img_bytes = (size_t)a.src_h * (size_t)a.src_w * (size_t)(C * sizeof(SrcT));
     DstT* drow = reinterpret_cast<DstT*>(a.dst + (long long)img * a.dst_img_stride) +
                  ((size_t)rr * (size_t)a.out_w + (size_t)c0) * C;
 
@@ -136,7 +144,7 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
             const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
             const bool valid = (xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1);
             if (valid) {
-                load_texel<SrcT, C>(simg, a.src_w, yi, xi, o);
+                load_texel<SrcT, C>(simg, img_bytes, a.src_w, yi, xi, o);
             } else {
 #pragma unroll
                 for (int k = 0; k < C; ++k) o[k] = 0.f;
@@ -151,10 +159,10 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
                 const float wy1 = (float)fy, wy0 = (float)(1.0 - fy);
                 const int ix1 = min(ix + 1, a.src_w - 1), iy1 = min(iy + 1, a.src_h - 1);
                 float p00[C], p01[C], p10[C], p11[C];
-                load_texel<SrcT, C>(simg, a.src_w, iy, ix, p00);
-                load_texel<SrcT, C>(simg, a.src_w, iy, ix1, p01);
-                load_texel<SrcT, C>(simg, a.src_w, iy1, ix, p10);
-                load_texel<SrcT, C>(simg, a.src_w, iy1, ix1, p11);
+                load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy, ix, p00);
+                load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy, ix1, p01);
+                load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix, p10);
+                load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix1, p11);
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
                     const float top = fmaf(p01[k], wx1, p00[k] * wx0);
@@ -187,11 +195,17 @@ template <typename K> int launch(K kernel, const WarpArgs& a, hipStream_t s);
 // ~4x slower than the fast kernel: it exists for parity, not for throughput.
 // ================================================================================================
 template <typename SrcT, int C>
-__device__ __forceinline__ void load_texel_f64(const unsigned char* img, int src_w, int iy, int ix, double (&t)[C]) {
+__device__ __forceinline__ void load_texel_f64(const unsigned char* img, size_t img_bytes, int src_w, int iy, int ix, double (&t)[C]) {
     const size_t off = ((size_t)iy * (size_t)src_w + (size_t)ix) * (size_t)(C * sizeof(SrcT));
     if constexpr (sizeof(SrcT) == 1) {
+        if (off + 4 <= img_bytes) {     // one unaligned 4-byte load covers an RGB / RGBA texel
+            const uint32_t v = ld4(img + off);
 #pragma unroll
-        for (int c = 0; c < C; ++c) t[c] = (double)img[off + c];
+            for (int c = 0; c < C; ++c) t[c] = (double)((v >> (8 * c)) & 0xffu);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[c] = (double)img[off + c];
+        }
     } else {
         const float* p = reinterpret_cast<const float*>(img + off);
 #pragma unroll
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(256) void warp_exact(const WarpArgs a) {
     const int c0 = ((int)tx * RWH_WAVE + lane) * PX;
     if (c0 >= a.out_w) return;
     const unsigned char* simg = a.src + (long long)img * a.src_img_stride;
+    const size_t img_bytes = (size_t)a.src_h * (size_t)a.src_w * (size_t)(C * sizeof(SrcT));
     DstT* drow = reinterpret_cast<DstT*>(a.dst + (long long)img * a.dst_img_stride) +
                  ((size_t)rr * (size_t)a.out_w + (size_t)c0) * C;
     const double y = grid_coord(r, a.out_h, a.y0, a.step_y, a.y_last);
@@ -244,10 +259,10 @@ __global__ __launch_bounds__(256) void warp_exact(const WarpArgs a) {
                 const double gx = 1.0 - fx, gy = 1.0 - fy;
                 const int ix1 = min(ix + 1, a.src_w - 1), iy1 = min(iy + 1, a.src_h - 1);
                 double p00[C], p01[C], p10[C], p11[C];
-                load_texel_f64<SrcT, C>(simg, a.src_w, iy, ix, p00);
-                load_texel_f64<SrcT, C>(simg, a.src_w, iy, ix1, p01);
-                load_texel_f64<SrcT, C>(simg, a.src_w, iy1, ix, p10);
-                load_texel_f64<SrcT, C>(simg, a.src_w, iy1, ix1, p11);
+                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy, ix, p00);
+                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy, ix1, p01);
+                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix, p10);
+                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix1, p11);
 #pragma unroll
                 for (int k = 0; k < C; ++k) {
                     const double top = p00[k] * gx + p01[k] * fx;   // contraction is off: three roundings, like numpy
