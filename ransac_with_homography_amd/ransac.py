@@ -3,7 +3,7 @@
 `HomoModel`, `RANSAC` and `stitching` keep the reference's names, constructor
 arguments, defaults, return values and data layout (features x observations,
 ransac.py:159-166).  The k-iteration Python loop of `RANSAC.run`
-(ransac.py:176-202) is replaced by three launches on the GPU:
+(ransac.py:176-202) is replaced by ONE library call, `rwh_ransac_search`, which enqueues
 
     K1  rwh_dlt4_batched   all k four-point DLT hypotheses        (ransac.py:178-180)
     K2  rwh_score_count    k x M reprojection errors, `err < th`,  (ransac.py:182-184)
