@@ -78,3 +78,18 @@ def test_host_solvers_match_goldens():
     assert np.array_equal(hg.calcHomographyLinear(u, v), z["H_linear"])
     assert np.array_equal(hg.calcHomography(u, v), z["H_dlt"])          # float64 inputs: host SVD path
     assert hg.calcH is hg.calcHomographyLinear and hg.perspectiveTransform is hg.wrapPerspective
+
+
+def test_plain_c_consumer(lib, tmp_path):
+    """include/rwh.h compiles as C and a gcc-built program links the library and gets the documented status codes."""
+    import subprocess
+    from ransac_with_homography_amd import _lib
+    exe = str(tmp_path / "cabi_smoke")
+    libdir = os.path.dirname(_lib.LIB_PATH)
+    torch_lib = os.path.join(os.path.dirname(__import__("torch").__file__), "lib")
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                    os.path.join(ROOT, "tests", "cabi", "cabi_smoke.c"), "-o", exe, "-L", libdir, "-lrwh_hip",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,-rpath," + torch_lib,
+                    "-Wl,--allow-shlib-undefined"], check=True)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True).stdout
+    assert "cabi ok" in out

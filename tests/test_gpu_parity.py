@@ -474,3 +474,35 @@ def test_exact_mode_photo_goldens_sha256(gpu, exact_mode):
     assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"])) == str(z["stitch_paste_sha256"])
     assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"], blending="Rate", blendrate=0.2)) == str(z["stitch_rate_sha256"])
     assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_g5"], blending="Rate", blendrate=0.2)) == str(z["stitch_g5_rate_sha256"])
+
+
+def test_entry_points_are_graph_capturable(gpu):
+    """The C entry points enqueue on the caller's stream and neither allocate nor synchronise: a hipGraph captured
+    around them (torch.cuda.CUDAGraph) replays to the eager result."""
+    from ransac_with_homography_amd import kernels
+    g = torch.Generator(device="cpu").manual_seed(3)
+    src = torch.randint(0, 256, (2, 240, 320, 3), dtype=torch.uint8, generator=g).to(gpu)
+    inv = np.linalg.inv(H_BENCH)
+    grid = kernels.Grid(0, 319, 320, 0, 239, 240)
+    eager = kernels.warp_backward(src, inv, grid, (240, 320), "bilinear", torch.uint8)
+    out = torch.zeros_like(eager)
+    z = load_golden("matchespoints")
+    pa, pb = torch.from_numpy(z["ptsA"]).to(gpu), torch.from_numpy(z["ptsB"]).to(gpu)
+    np.random.seed(0)
+    idx = torch.from_numpy(np.random.randint(0, 185, (2000, 4)).astype(np.int32)).to(gpu)
+    ws = kernels.SearchWorkspace(2000, 185, gpu)
+    kernels.ransac_search(pa, pb, idx, 5.0, "fwd", 134, ws)
+    ref_best = ws.best.clone(); ref_counts = ws.counts.clone()
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):       # warm-up on the side stream, as graph capture requires
+        kernels.warp_backward(src, inv, grid, (240, 320), "bilinear", torch.uint8, out=out)
+        kernels.ransac_search(pa, pb, idx, 5.0, "fwd", 134, ws)
+    s.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s):
+        kernels.warp_backward(src, inv, grid, (240, 320), "bilinear", torch.uint8, out=out)
+        kernels.ransac_search(pa, pb, idx, 5.0, "fwd", 134, ws)
+    out.zero_(); ws.best.zero_(); ws.counts.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out, eager) and torch.equal(ws.best, ref_best) and torch.equal(ws.counts, ref_counts)
