@@ -321,13 +321,13 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // Fast-path launch (RGB u8, bilinear): returns RWH_E_UNSUPPORTED when the shape needs the generic kernel.
 // px8: 8 pixels per lane (128 x 16 block tiles) instead of 4 (256 x 4).
 // variant: 0 = 4 px per lane (256 x 4 block tiles), 1 = 8 px per lane (128 x 16 block tiles).
-// (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on 128 x 16*group block tiles.)
+// (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on the 8 px kernel's 128 x 16 block tiles.)
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
                 int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
                 void (*custom)(const FastArgs) = nullptr) {
     const bool px8 = variant >= 1;
     const int lane_px = px8 ? F8_PX : FP_PX;
-    if (w.out_w < lane_px || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
+    if (w.out_w < (px8 ? 128 : lane_px) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
     const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
     if ((size_t)w.rows * (size_t)w.out_w * 3 * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
     FastArgs a;
@@ -335,9 +335,13 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.cx[0] = ih[0] * x0 + ih[1] * y0 + ih[2]; a.cx[1] = ih[1] * step_y; a.cx[2] = ih[0] * step_x;
     a.cy[0] = ih[3] * x0 + ih[4] * y0 + ih[5]; a.cy[1] = ih[4] * step_y; a.cy[2] = ih[3] * step_x;
     a.cw[0] = ih[6] * x0 + ih[7] * y0 + ih[8]; a.cw[1] = ih[7] * step_y; a.cw[2] = ih[6] * step_x;
-    for (int j = 1; j <= 7; ++j) {
-        const double d[3] = {(double)j * a.cx[2], (double)j * a.cy[2], (double)j * a.cw[2]};
-        for (int q = 0; q < 3; ++q) { a.dxs8[j - 1][q] = d[q]; if (j <= 3) a.dxs[j - 1][q] = d[q]; }
+    for (int j = 1; j <= 7; ++j) {   // column offsets of a lane's pixels: 1..3 (4 px kernel); 1..3, 64..67 (8 px kernel)
+        const double o4 = (double)j, o8 = (double)(j < 4 ? j : 60 + j);
+        for (int q = 0; q < 3; ++q) {
+            const double c = q == 0 ? a.cx[2] : q == 1 ? a.cy[2] : a.cw[2];
+            a.dxs8[j - 1][q] = o8 * c;
+            if (j <= 3) a.dxs[j - 1][q] = o4 * c;
+        }
     }
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
@@ -345,8 +349,8 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
     a.row_begin = w.row_begin; a.rows = w.rows;
     a.tiles_x = (unsigned)(px8 ? (w.out_w + 127) / 128 : (w.out_w + 255) / 256);
-    a.group = variant == 2 ? group : 1;
-    a.tiles_y = (unsigned)(px8 ? (w.rows + 16 * a.group - 1) / (16 * a.group) : (w.rows + 3) / 4);
+    a.group = group;   // free parameter of a tools/warp_lab custom kernel
+    a.tiles_y = (unsigned)(px8 ? (w.rows + 15) / 16 : (w.rows + 3) / 4);
     const unsigned long long nb = (unsigned long long)a.tiles_x * a.tiles_y * (unsigned)batch;
     if (nb >= (1ull << 31) / 8) return RWH_E_UNSUPPORTED;
     a.nblocks = (unsigned)nb;

@@ -343,13 +343,19 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
 // Same arithmetic as warp_rgb8_fast, but the per-lane overhead (patch decode, coordinate setup, footprint,
 // staging set-up) is shared by twice as many pixels.
 constexpr int F8_PX = 8;
-constexpr int F8_LANES = 21;                           // staging lanes per source row, 8 texels (24 B) each
+constexpr int F8_LANES = 21;                           // staging lanes per source row, 2 x 4 texels (2 x 12 B) each
 constexpr int F8_TEXELS = 8 * F8_LANES;                // 168 texels per staged row
 constexpr int F8_PITCH = 4 * F8_TEXELS + 16;           // 688 B per staged row
 
 #ifndef RWH_F8_WAVES
 #define RWH_F8_WAVES 1
 #endif
+// Order of work inside a wave: the two END pixels of every lane (own reciprocals) give the footprint and the staging
+// loads go out at once; the other six pixels are computed run by run (3 + 3, one batch inversion each) right before
+// their taps are read, so that only 4 pixels' coordinates, weights and taps are live at a time -- the kernel is
+// occupancy-sensitive (time ~ 9.5 + 35/n us per 4K frame for n resident waves per SIMD, n <= 5 measured) and this
+// keeps it at RWH_F8_WAVES waves.  The end pixels are computed once, so the footprint and the taps can never disagree
+// about a floor().
 template <typename DstT>
 __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * F8_PITCH];
@@ -364,75 +370,75 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     const unsigned ty = t - img * a.tiles_y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int prow = lane >> 4, pq = lane & 15;               // patch row 0..3, 4-pixel column group 0..15
+    const int prow = lane >> 4, pq = lane & 15;               // patch row 0..3, 8-pixel column group 0..15
 
     const int rr_raw = ((int)ty * 4 + wave) * 4 + prow;
     const int rr = min(rr_raw, a.rows - 1);                   // rows past the shard recompute its last row
-    const int c0 = (int)tx * 128 + pq * F8_PX;
-    const int c0p = min(c0, a.out_w - F8_PX);                 // columns past the row end recompute its last 8 px
-    const int shift = c0 - c0p;
-    const bool store_any = (rr_raw < a.rows) & (c0 < a.out_w);
+    // a lane owns two runs of 4 pixels, 64 pixels apart: every store instruction then writes 16 lanes x 12 B = 192
+    // contiguous bytes per patch row (8 contiguous pixels per lane would leave 12-byte holes in every store).
+    // A tile that sticks out of the row is moved left as a whole and owns only the columns >= its nominal start.
+    const int tcol0 = (int)tx * 128;
+    const int tcol = min(tcol0, a.out_w - 128);
+    const int tshift = tcol0 - tcol;                          // uniform
+    const int c0p = tcol + pq * 4;
+    const bool store_any = rr_raw < a.rows;
 
     const unsigned char* simg = a.src + (long long)img * a.src_img_stride;       // uniform
     unsigned char* dimg = a.dst + (long long)img * a.dst_img_stride;              // uniform
     // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
     DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
-
-    // ---- source coordinates of the lane's 4 pixels -----------------------------------------------
-#ifdef RWH_ABL_STORE_SMALL  // tools/warp_lab ablation hook: all stores land in a 200 KB window (stays in L2)
-    drow = reinterpret_cast<DstT*>(dimg + (uint32_t)(lane * 24 + wave * 1536 + (blockIdx.x & 31) * 6144));
-#endif
-    const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
-    double X[F8_PX], Y[F8_PX], W[F8_PX];
-    X[0] = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
-    Y[0] = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
-    W[0] = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
-#pragma unroll
-    for (int j = 1; j < F8_PX; ++j) {
-        X[j] = X[0] + a.dxs8[j - 1][0];
-        Y[j] = Y[0] + a.dxs8[j - 1][1];
-        W[j] = W[0] + a.dxs8[j - 1][2];
-    }
-    double rc[F8_PX];
-    // W is affine along a row, so W[0] > 0 and W[7] > 0 make all eight positive; with a finite, normal product
-    // the eight reciprocals come from ONE v_rcp_f64 (Montgomery batch inversion).  `wpos` is wave-uniform.
-    const double p01 = W[0] * W[1], p23 = W[2] * W[3], p45 = W[4] * W[5], p67 = W[6] * W[7];
-    const double pa = p01 * p23, pb = p45 * p67, P = pa * pb;
-    const bool wpos = __all((int)__builtin_amdgcn_class(P, 0x100) & (int)((int)hi32(W[0]) > 0) & (int)((int)hi32(W[F8_PX - 1]) > 0));
-    if (wpos) {
-        double rp = __builtin_amdgcn_rcp(P);
-        rp = fma(fma(-P, rp, 1.0), rp, rp);
-        const double ra = rp * pb, rb = rp * pa;              // 1/pa, 1/pb
-        const double r01 = ra * p23, r23 = ra * p01, r45 = rb * p67, r67 = rb * p45;
-        rc[0] = r01 * W[1]; rc[1] = r01 * W[0]; rc[2] = r23 * W[3]; rc[3] = r23 * W[2];
-        rc[4] = r45 * W[5]; rc[5] = r45 * W[4]; rc[6] = r67 * W[7]; rc[7] = r67 * W[6];
-    } else {                                                      // a W at / across zero (the horizon): pixel by pixel
-#pragma unroll
-        for (int j = 0; j < F8_PX; ++j) {
-            double q = __builtin_amdgcn_rcp(W[j]);
-            rc[j] = fma(fma(-W[j], q, 1.0), q, q);
-        }
-    }
-    uint32_t lx[F8_PX], ly[F8_PX], hx[F8_PX], hy[F8_PX];
-    unsigned long long ubx[F8_PX], uby[F8_PX];
-#pragma unroll
-    for (int j = 0; j < F8_PX; ++j) {
-        const double ux = X[j] * rc[j] + MAGIC;
-        const double uy = Y[j] * rc[j] + MAGIC;
-        ubx[j] = (unsigned long long)__double_as_longlong(ux);
-        uby[j] = (unsigned long long)__double_as_longlong(uy);
-        lx[j] = lo32(ux); ly[j] = lo32(uy);
-        hx[j] = hi32(ux); hy[j] = hi32(uy);
-    }
     const uint32_t pitch = (uint32_t)a.src_w * 3u;
+
+    // ---- pixels 0 and 7 of the lane: own reciprocal ------------------------------------------------------------
+    const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
+    const double X0 = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
+    const double Y0 = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
+    const double W0 = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+    uint32_t ehx[2], ehy[2], elx[2], ely[2];                  // the lane's first and last pixel
+    bool wpos;
+    {
+        const double X7 = X0 + a.dxs8[6][0], Y7 = Y0 + a.dxs8[6][1], W7 = W0 + a.dxs8[6][2];
+        double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
+        double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
+        const double ux0 = X0 * r0 + MAGIC, uy0 = Y0 * r0 + MAGIC, ux7 = X7 * r7 + MAGIC, uy7 = Y7 * r7 + MAGIC;
+        ehx[0] = hi32(ux0); elx[0] = lo32(ux0); ehy[0] = hi32(uy0); ely[0] = lo32(uy0);
+        ehx[1] = hi32(ux7); elx[1] = lo32(ux7); ehy[1] = hi32(uy7); ely[1] = lo32(uy7);
+        // W is affine along a row: positive at both ends of every lane's span <=> positive on the whole patch
+        wpos = __all((int)((int)hi32(W0) > 0) & (int)((int)hi32(W7) > 0));
+    }
+    // run h (0: pixels 0..3, 1: pixels 4..7 = columns +64..+67): the three pixels that are not an end pixel share
+    // one reciprocal (batch inversion); registers are reused between the runs
+    uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
+    auto run_coords = [&](const int h) {
+        double X[3], Y[3], W[3], rc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + a.dxs8[3 * h + j][0]; Y[j] = Y0 + a.dxs8[3 * h + j][1]; W[j] = W0 + a.dxs8[3 * h + j][2]; }
+        const double p12 = W[0] * W[1], P = p12 * W[2];
+        if (wpos & (bool)__all((int)__builtin_amdgcn_class(P, 0x100))) {   // finite, normal product of positive W
+            double rp = __builtin_amdgcn_rcp(P);
+            rp = fma(fma(-P, rp, 1.0), rp, rp);
+            const double r12 = rp * W[2];
+            rc[2] = rp * p12; rc[0] = r12 * W[1]; rc[1] = r12 * W[0];
+        } else {                                                           // a W at / across zero (the horizon)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) { double q = __builtin_amdgcn_rcp(W[j]); rc[j] = fma(fma(-W[j], q, 1.0), q, q); }
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double ux = X[j] * rc[j] + MAGIC, uy = Y[j] * rc[j] + MAGIC;
+            const int q = j + 1 - h;
+            hx[q] = hi32(ux); lx[q] = lo32(ux); hy[q] = hi32(uy); ly[q] = lo32(uy);
+        }
+        hx[3 * h] = ehx[h]; lx[3 * h] = elx[h]; hy[3 * h] = ehy[h]; ly[3 * h] = ely[h];
+    };
 
     // ---- wave-uniform footprint from the four patch corners (lanes 0, 15, 48, 63), on the scalar unit ----
     // hi dwords compare like the integers they encode (same exponent); out-of-range / NaN corners end up
     // as the min or the max and fail the range test below.
-    const int x0 = (int)__builtin_amdgcn_readlane(hx[0], 0), x1 = (int)__builtin_amdgcn_readlane(hx[F8_PX - 1], 15);
-    const int x2 = (int)__builtin_amdgcn_readlane(hx[0], 48), x3 = (int)__builtin_amdgcn_readlane(hx[F8_PX - 1], 63);
-    const int y0 = (int)__builtin_amdgcn_readlane(hy[0], 0), y1 = (int)__builtin_amdgcn_readlane(hy[F8_PX - 1], 15);
-    const int y2 = (int)__builtin_amdgcn_readlane(hy[0], 48), y3 = (int)__builtin_amdgcn_readlane(hy[F8_PX - 1], 63);
+    const int x0 = (int)__builtin_amdgcn_readlane(ehx[0], 0), x1 = (int)__builtin_amdgcn_readlane(ehx[1], 15);
+    const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 48), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], 15);
+    const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 48), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
     const int xa = min(x0, x1), xb = min(x2, x3), xc = max(x0, x1), xd = max(x2, x3);
     const int ya = min(y0, y1), yb = min(y2, y3), yc = max(y0, y1), yd = max(y2, y3);
     const int hxmn = __builtin_amdgcn_readfirstlane(min(xa, xb)), hxmx = __builtin_amdgcn_readfirstlane(max(xc, xd));
@@ -444,54 +450,55 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) &
                         (ymx < min(a.bound_h - 1, a.src_h - 2)) & (ymx - ymn + 2 <= FP_ROWS) & (xmx - xmn + 2 <= F8_TEXELS);
 
+    // ---- staging loads go out now ----------------------------------------------------------------------------------
+    unsigned char* my = slab[wave];
+    // staging lane -> (source row srow of 3, texel group scol of 21): 24 packed bytes in, 8 RGBX texels out
+    const int srow = (lane * 49) >> 10;                     // lane / 21 for lane < 64
+    const int scol = lane - F8_LANES * srow;
+    // each row segment is read by two instructions of 21 lanes x 12 contiguous bytes (texels 0..83 and 84..167)
+    pk3 va[FP_ROWS / 3], vb[FP_ROWS / 3];
+    bool ona[FP_ROWS / 3], onb[FP_ROWS / 3];
+    if (staged) {
+        const int nrows = ymx - ymn + 2, ntex = xmx - xmn + 2;
+        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+        const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 12u;
+        const bool mine_a = (srow < 3) & (4 * scol < ntex), mine_b = (srow < 3) & (4 * scol + F8_TEXELS / 2 < ntex);
+#pragma unroll
+        for (int k = 0; k < FP_ROWS / 3; ++k) {
+            ona[k] = mine_a & (3 * k + srow < nrows);
+            onb[k] = mine_b & (3 * k + srow < nrows);
+            va[k] = pk3{0u, 0u, 0u}; vb[k] = pk3{0u, 0u, 0u};
+#ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
+            va[k] = pk3{goff, goff * 3u, goff * 5u}; vb[k] = pk3{goff * 7u, goff * 11u, goff * 13u};
+#else
+            if (ona[k]) __builtin_memcpy(&va[k], gbase + (size_t)(3 * k) * pitch + goff, 12);
+            if (onb[k]) __builtin_memcpy(&vb[k], gbase + (size_t)(3 * k) * pitch + goff + 3 * (F8_TEXELS / 2), 12);
+#endif
+        }
+    }
+
     uint32_t a0[FP_PX], b0[FP_PX], a1[FP_PX], b1[FP_PX];
     float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
     if (staged) {
-        const int nrows = ymx - ymn + 2, ntex = xmx - xmn + 2;
-        unsigned char* my = slab[wave];
-        // staging lane -> (source row srow of 3, texel group scol of 21): 24 packed bytes in, 8 RGBX texels out
-        const int srow = (lane * 49) >> 10;                     // lane / 21 for lane < 64
-        const int scol = lane - F8_LANES * srow;
-#ifdef RWH_ABL_LOAD_SMALL   // tools/warp_lab ablation hook: all staging loads come from the first 64 source rows
-        const unsigned char* gbase = simg + (size_t)((uint32_t)(ymn & 63) * pitch + (uint32_t)xmn * 3u);
-#else
-        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
-#endif
-        const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 24u;
-        unsigned char* wlds = my + srow * F8_PITCH + scol * 32;
-        const bool mine = (srow < 3) & (8 * scol < ntex);
-        // all staging loads are issued before the first LDS write so that their latencies overlap
-        pk4 va[FP_ROWS / 3];
-        pk2 vb[FP_ROWS / 3];
-        bool on[FP_ROWS / 3];
-#pragma unroll
-        for (int k = 0; k < FP_ROWS / 3; ++k) {
-            on[k] = mine & (3 * k + srow < nrows);
-            va[k] = pk4{0u, 0u, 0u, 0u}; vb[k] = pk2{0u, 0u};
-#ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
-            va[k] = pk4{goff, goff * 3u, goff * 5u, goff * 7u}; vb[k] = pk2{goff * 11u, goff * 13u};
-#else
-            if (on[k]) {
-                __builtin_memcpy(&va[k], gbase + (size_t)(3 * k) * pitch + goff, 16);
-                __builtin_memcpy(&vb[k], gbase + (size_t)(3 * k) * pitch + goff + 16, 8);
-            }
-#endif
-        }
+        unsigned char* wlds = my + srow * F8_PITCH + scol * 16;
         const uint32_t lds_c = (uint32_t)hymn * (uint32_t)F8_PITCH + (uint32_t)hxmn * 4u;  // uniform
 #pragma unroll
         for (int k = 0; k < FP_ROWS / 3; ++k) {
-            if (on[k]) {
-                uint4 t4, t5;
+            if (ona[k]) {                                       // 12 packed bytes -> 4 RGBX texels
+                uint4 t4;
                 t4.x = va[k].a;
                 t4.y = __builtin_amdgcn_alignbyte(va[k].b, va[k].a, 3);
                 t4.z = __builtin_amdgcn_alignbyte(va[k].c, va[k].b, 2);
                 t4.w = va[k].c >> 8;
-                t5.x = va[k].d;
-                t5.y = __builtin_amdgcn_alignbyte(vb[k].a, va[k].d, 3);
-                t5.z = __builtin_amdgcn_alignbyte(vb[k].b, vb[k].a, 2);
-                t5.w = vb[k].b >> 8;
                 *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH) = t4;
-                *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH + 16) = t5;
+            }
+            if (onb[k]) {
+                uint4 t5;
+                t5.x = vb[k].a;
+                t5.y = __builtin_amdgcn_alignbyte(vb[k].b, vb[k].a, 3);
+                t5.z = __builtin_amdgcn_alignbyte(vb[k].c, vb[k].b, 2);
+                t5.w = vb[k].c >> 8;
+                *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH + 2 * F8_TEXELS) = t5;
             }
         }
         // the slab is wave-private: order this wave's LDS writes before its LDS reads, no block barrier
@@ -499,10 +506,11 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                           // two halves of 4 pixels: registers are reused
+        for (int h = 0; h < 2; ++h) {                           // the two runs of 4 pixels: registers are reused
+            run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
-                const int q = 4 * h + j;
+                const int q = j;
                 wx1[j] = (float)lx[q]; wx0[j] = (float)(~lx[q]);
                 wy1[j] = (float)ly[q] * W_SCALE; wy0[j] = (float)(~ly[q]) * W_SCALE;
                 const uint32_t lo = hy[q] * (uint32_t)F8_PITCH + hx[q] * 4u - lds_c;
@@ -514,7 +522,8 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
 #endif
             }
             // lane owns local pixels q >= shift; a half is stored whole when shift <= 4*h
-            blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 12 * h, store_any & (shift < 4 * h + 4), max(shift - 4 * h, 0));
+            const int first = tshift - (64 * h + 4 * pq);       // local pixels j >= first are this tile's
+            blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 192 * h, store_any & (first < 4), max(first, 0));
         }
         return;
     }
@@ -524,10 +533,14 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     for (int h = 0; h < 2; ++h) {
         uint32_t off[FP_PX];
         bool near_end = false;
+        run_coords(h);
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j) {
-            const int q = 4 * h + j;
-            const bool valid = (ubx[q] >= MAGIC_BITS) & (ubx[q] <= a.xmax_bits) & (uby[q] >= MAGIC_BITS) & (uby[q] <= a.ymax_bits);
+            const int q = j;
+            // 0 <= s <= bound-1 on the bit patterns: positive doubles order like unsigned integers; negative
+            // values and NaNs have patterns outside [MAGIC_BITS, xmax_bits]
+            const unsigned long long ubx = ((unsigned long long)hx[q] << 32) | lx[q], uby = ((unsigned long long)hy[q] << 32) | ly[q];
+            const bool valid = (ubx >= MAGIC_BITS) & (ubx <= a.xmax_bits) & (uby >= MAGIC_BITS) & (uby <= a.ymax_bits);
             const float sc = valid ? W_SCALE : 0.f;
             const int ix = (int)(hx[q] - MAGIC_HI), iy = (int)(hy[q] - MAGIC_HI);
             wx1[j] = (float)lx[q]; wx0[j] = (float)(~lx[q]);
@@ -555,10 +568,10 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
                 b1[j] = simg[o11] | (simg[o11 + 1] << 8) | (simg[o11 + 2] << 16);
             }
         }
-        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 12 * h, store_any & (shift < 4 * h + 4), max(shift - 4 * h, 0));
+        const int first = tshift - (64 * h + 4 * pq);
+        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 192 * h, store_any & (first < 4), max(first, 0));
     }
 }
-
 
 // floor(n / d) == umulhi(n, magic) for every n < n_max, or 0 if no such 32-bit magic exists
 inline unsigned div_magic(unsigned d, unsigned long long n_max) {

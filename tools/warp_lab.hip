@@ -5,7 +5,6 @@
 // 3840x2160 fixed grid) and reports how many output bytes differ from the generic (reference-order,
 // texel-exact) kernel.
 #include "../ransac_with_homography_amd/csrc/rwh_warp.hip"
-#include "warp_pipe_experiment.h"
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -36,6 +35,65 @@ __global__ void diff_count(const unsigned char* a, const unsigned char* b, size_
 }
 
 // calibration: plain copies of the same volume (what the memory system delivers with no arithmetic)
+
+// Memory-pattern twin of warp_rgb8_fast8: the same grid, the same staging-load and output-store instruction shapes
+// (6 source rows x 132 texels in, 4 rows x 128 px out per wave), LDS round trip, and ALU work replaced by NALU
+// dependent FMAs per lane.  Answers: what does this access pattern cost with no / with the real amount of arithmetic?
+template <int NALU, int MODE = 0>   // MODE 1: loads only, 2: stores only
+__global__ __launch_bounds__(256) void pattern_twin(const FastArgs a) {
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * F8_PITCH];
+    const unsigned b = blockIdx.x;
+    const unsigned logical = (b & 7u) * a.cpx + (b >> 3);
+    if (logical >= a.nblocks) return;
+    const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;
+    const unsigned tx = logical - t * a.tiles_x;
+    const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
+    const unsigned ty = t - img * a.tiles_y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63, prow = lane >> 4, pq = lane & 15;
+    const int rr = min(((int)ty * 4 + wave) * 4 + prow, a.rows - 1);
+    const int tcol = min((int)tx * 128, a.out_w - 128);
+    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;
+    unsigned char* drow = a.dst + (long long)img * a.dst_img_stride + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)(tcol + 4 * pq)) * 3u;
+    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+    const int srow = (lane * 49) >> 10, scol = lane - 21 * srow;
+    const int r0 = min(((int)ty * 4 + wave) * 4 + 5, a.src_h - 8), x0 = tcol + 3;   // footprint origin (like the warp: a few px off)
+    const unsigned char* gbase = simg + (size_t)((uint32_t)r0 * pitch + (uint32_t)x0 * 3u);
+    const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 12u;
+    pk3 va[2], vb[2];
+    const bool ona = srow < 3, onb = (srow < 3) & (4 * scol + 84 < 132);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        va[k] = pk3{0, 0, 0}; vb[k] = pk3{0, 0, 0};
+        if (MODE != 2) {
+            if (ona) __builtin_memcpy(&va[k], gbase + (size_t)(3 * k) * pitch + goff, 12);
+            if (onb) __builtin_memcpy(&vb[k], gbase + (size_t)(3 * k) * pitch + goff + 252, 12);
+        } else { va[k] = pk3{goff, goff * 3u, goff * 5u}; vb[k] = pk3{goff * 7u, goff * 11u, goff * 13u}; }
+    }
+    float f = (float)lane;
+#pragma unroll 16
+    for (int i = 0; i < NALU / 2; ++i) f = fmaf(f, 1.0001f, 0.5f);
+    unsigned char* my = slab[wave];
+    unsigned char* wlds = my + srow * F8_PITCH + scol * 16;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (ona) *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH) = uint4{va[k].a, va[k].b, va[k].c, va[k].a};
+        if (onb) *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH + 336) = uint4{vb[k].a, vb[k].b, vb[k].c, vb[k].a};
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 16
+    for (int i = 0; i < NALU / 2; ++i) f = fmaf(f, 1.0001f, 0.5f);
+    const uint32_t fx = __float_as_uint(f) & 1u;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const uint32_t* t0 = reinterpret_cast<const uint32_t*>(my + prow * F8_PITCH + (64 * h + 4 * pq) * 4);
+        pk3 w = {t0[0] ^ fx, t0[1], t0[2] + t0[F8_PITCH / 4]};
+        if (MODE != 1 || w.a + w.b + w.c == 0x12345u) __builtin_memcpy(drow + 192 * h, &w, 12);
+    }
+}
+
 __global__ __launch_bounds__(256) void copy16(const uint4* __restrict__ s, uint4* __restrict__ d, size_t n) {
     size_t i = blockIdx.x * (size_t)256 + threadIdx.x;
     if (i < n) d[i] = s[i];
@@ -49,7 +107,14 @@ int main(int argc, char** argv) {
     const int B = argc > 1 ? atoi(argv[1]) : 16;
     const char* filter = argc > 2 ? argv[2] : nullptr;
     const int SH = 2160, SW = 3840;
-    const double H[9] = {1.02, 0.01, 5.0, 0.015, 0.98, 7.0, 1e-5, 2e-5, 1.0};
+    double H[9] = {1.02, 0.01, 5.0, 0.015, 0.98, 7.0, 1e-5, 2e-5, 1.0};
+    if (const char* rot = getenv("LAB_ROT")) {   // rotation by LAB_ROT degrees about the image centre, scale LAB_SCALE (default 1)
+        const double th = atof(rot) * 3.14159265358979323846 / 180.0, sc = getenv("LAB_SCALE") ? atof(getenv("LAB_SCALE")) : 1.0;
+        const double c = sc * cos(th), sn = sc * sin(th), cx = 0.5 * (SW - 1), cy = 0.5 * (SH - 1);
+        const double R[9] = {c, -sn, cx - c * cx + sn * cy, sn, c, cy - sn * cx - c * cy, 0, 0, 1};
+        for (int i = 0; i < 9; ++i) H[i] = R[i];
+        printf("H = rotation %s deg, scale %.3f about the centre\n", rot, sc);
+    }
     double A[3][6], ih[9];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = H[3 * i + j]; A[i][3 + j] = i == j; }
     for (int c = 0; c < 3; ++c) {
@@ -104,7 +169,7 @@ int main(int argc, char** argv) {
             a.src = src; a.dst = dst; a.src_img_stride = (long long)src_bytes; a.dst_img_stride = (long long)G.w * G.h * 3;
             a.src_h = SH; a.src_w = SW; a.bound_h = SH; a.bound_w = SW; a.out_h = G.h; a.out_w = G.w; a.row_begin = 0; a.rows = G.h;
             return launch_fast(a, ih, G.x0, 1.0, G.y0, 1.0, RWH_U8, B, (hipStream_t)0, variant, group,
-                               variant == 2 ? warp_rgb8_pipe<unsigned char> : nullptr);
+                               variant == 2 ? (group == 0 ? pattern_twin<0> : group == 1 ? pattern_twin<220> : group == 2 ? pattern_twin<440> : group == 3 ? pattern_twin<0, 1> : pattern_twin<0, 2>) : nullptr);
         };
         struct Case { const char* name; std::function<int()> run; };
         std::vector<Case> cases = {
@@ -115,9 +180,11 @@ int main(int argc, char** argv) {
                                          G.y0 + G.h - 1, G.h, G.w, SH, SW, RWH_BILINEAR, dst, RWH_U8, (int64_t)G.w * G.h * 3, 0, G.h, RWH_WARP_EXACT, nullptr); }},
             {"fast u8 px4", [&] { return fast(0, 1); }},
             {"fast u8 px8", [&] { return fast(1, 1); }},
-            {"fast u8 pipe G=4", [&] { return fast(2, 4); }},
-            {"fast u8 pipe G=8", [&] { return fast(2, 8); }},
-            {"fast u8 pipe G=16", [&] { return fast(2, 16); }},
+            {"twin: px8 access pattern, no ALU", [&] { return fast(2, 0); }},
+            {"twin: px8 access pattern + 220 FMA", [&] { return fast(2, 1); }},
+            {"twin: px8 access pattern + 440 FMA", [&] { return fast(2, 2); }},
+            {"twin: loads only", [&] { return fast(2, 3); }},
+            {"twin: stores only", [&] { return fast(2, 4); }},
         };
         const double bytes = (double)B * (src_bytes + (double)G.w * G.h * 3);
         const size_t nbytes = (size_t)G.w * G.h * 3 * B;
