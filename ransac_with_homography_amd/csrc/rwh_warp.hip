@@ -15,6 +15,7 @@
 //     of output tile rows: vertically adjacent tiles share source rows in one L2;
 //   * no MFMA: there is no dense contraction in this path.
 #include "rwh_common.h"
+#include <cstdlib>
 #include "rwh_warp_rgb8.h"
 
 namespace rwh {
@@ -318,16 +319,43 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
         for (int i = 0; i < nbytes; ++i) src[(long long)b * stride + i] = 0;
 }
 
+// Patch shape of the 8 px kernel (log2 of the patch width: 7, 6 or 5).  Over a 5 x 5 sample of patch positions, a shape
+// qualifies if its source footprints fit the LDS slab (nearly) everywhere; among those the one whose staging loads touch
+// the fewest 128-byte lines wins (a 128 x 4 patch rotated by 90 degrees "fits", but as 130 rows of 6 texels), the wider
+// shape on a near tie (longer contiguous stores).  RWH_WARP_SHAPE=5|6|7 in the environment overrides (tests, lab).
+static int choose_shape(const FastArgs& a) {
+    if (const char* e = getenv("RWH_WARP_SHAPE")) {
+        const int v = atoi(e);
+        if (v >= 5 && v <= 7) return v;
+    }
+    int best = 7;
+    double best_lines = 1e300;
+    for (int lp = 7; lp >= 5; --lp) {
+        const int pw = 1 << lp, ph = 512 >> lp;
+        int seen = 0, fit = 0;
+        double lines_sum = 0;
+        for (int i = 0; i < 5; ++i)
+            for (int j = 0; j < 5; ++j) {
+                const double r = (a.rows > ph ? (a.rows - ph) * (i / 4.0) : 0.0), c = (a.out_w > pw ? (a.out_w - pw) * (j / 4.0) : 0.0);
+                long long ch; double ln;
+                if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &ch, &ln)) continue;   // horizon: gathers anyway
+                ++seen; fit += ch <= F8_CHUNKS; lines_sum += ln;
+            }
+        if (seen == 0) return 7;
+        if (10 * fit < 9 * seen) continue;
+        if (lines_sum < 0.95 * best_lines) { best = lp; best_lines = lines_sum; }
+    }
+    return best;   // nothing fits (strong zoom-out): every wave gathers; 7 has the longest stores
+}
+
 // Fast-path launch (RGB u8, bilinear): returns RWH_E_UNSUPPORTED when the shape needs the generic kernel.
-// px8: 8 pixels per lane (128 x 16 block tiles) instead of 4 (256 x 4).
-// variant: 0 = 4 px per lane (256 x 4 block tiles), 1 = 8 px per lane (128 x 16 block tiles).
+// variant: 0 = 4 px per lane (256 x 4 block tiles), 1 = 8 px per lane (128 x 16 block tiles, patch shape chosen here).
 // (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on the 8 px kernel's 128 x 16 block tiles.)
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
                 int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
                 void (*custom)(const FastArgs) = nullptr) {
     const bool px8 = variant >= 1;
-    const int lane_px = px8 ? F8_PX : FP_PX;
-    if (w.out_w < (px8 ? 128 : lane_px) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
+    if (w.out_w < (px8 ? 128 : FP_PX) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
     const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
     if ((size_t)w.rows * (size_t)w.out_w * 3 * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
     FastArgs a;
@@ -335,8 +363,11 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.cx[0] = ih[0] * x0 + ih[1] * y0 + ih[2]; a.cx[1] = ih[1] * step_y; a.cx[2] = ih[0] * step_x;
     a.cy[0] = ih[3] * x0 + ih[4] * y0 + ih[5]; a.cy[1] = ih[4] * step_y; a.cy[2] = ih[3] * step_x;
     a.cw[0] = ih[6] * x0 + ih[7] * y0 + ih[8]; a.cw[1] = ih[7] * step_y; a.cw[2] = ih[6] * step_x;
-    for (int j = 1; j <= 7; ++j) {   // column offsets of a lane's pixels: 1..3 (4 px kernel); 1..3, 64..67 (8 px kernel)
-        const double o4 = (double)j, o8 = (double)(j < 4 ? j : 60 + j);
+    a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
+    a.row_begin = w.row_begin; a.rows = w.rows;
+    const int shape = px8 ? choose_shape(a) : 0;
+    for (int j = 1; j <= 7; ++j) {   // column offsets of a lane's pixels: 1..3 (4 px kernel); 1..3, PW/2 .. PW/2+3 (8 px kernel)
+        const double o4 = (double)j, o8 = (double)(j < 4 ? j : (px8 ? (1 << shape) / 2 : 4) + j - 4);
         for (int q = 0; q < 3; ++q) {
             const double c = q == 0 ? a.cx[2] : q == 1 ? a.cy[2] : a.cw[2];
             a.dxs8[j - 1][q] = o8 * c;
@@ -346,8 +377,6 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
     __builtin_memcpy(&a.ymax_bits, &ym, 8);
-    a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
-    a.row_begin = w.row_begin; a.rows = w.rows;
     a.tiles_x = (unsigned)(px8 ? (w.out_w + 127) / 128 : (w.out_w + 255) / 256);
     a.group = group;   // free parameter of a tools/warp_lab custom kernel
     a.tiles_y = (unsigned)(px8 ? (w.rows + 15) / 16 : (w.rows + 3) / 4);
@@ -359,15 +388,15 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.tiles_y_magic = div_magic(a.tiles_y, nb / a.tiles_x + 1);
     if ((a.tiles_x > 1 && !a.tiles_x_magic) || (a.tiles_y > 1 && !a.tiles_y_magic)) return RWH_E_UNSUPPORTED;
     const dim3 grid(8u * a.cpx), block(256);
-    if (custom) {
-        hipLaunchKernelGGL(custom, grid, block, 0, s, a);
-    } else if (px8) {
-        if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_fast8<unsigned char>, grid, block, 0, s, a);
-        else hipLaunchKernelGGL(warp_rgb8_fast8<float>, grid, block, 0, s, a);
-    } else {
-        if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_fast<unsigned char>, grid, block, 0, s, a);
-        else hipLaunchKernelGGL(warp_rgb8_fast<float>, grid, block, 0, s, a);
+    void (*kern)(const FastArgs) = custom;
+    if (!kern) {
+        const bool u8 = dst_dtype == RWH_U8;
+        if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
+        else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
+        else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
+        else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
     }
+    hipLaunchKernelGGL(kern, grid, block, 0, s, a);
     return check_launch();
 }
 

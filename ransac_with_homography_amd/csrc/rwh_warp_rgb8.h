@@ -54,13 +54,13 @@ struct FastArgs {
     // X = cx[0] + row*cx[1] + col*cx[2] for output (row, col); likewise Y, W   (float64, host-built)
     double cx[3], cy[3], cw[3];
     double dxs[3][3];                                    // dxs[j-1] = j * (cx[2], cy[2], cw[2])
-    double dxs8[7][3];                                   // same for the 8-pixel-per-lane kernel
+    double dxs8[7][3];                                   // 8 px kernel: column offsets 1, 2, 3, PW/2 .. PW/2+3 of the patch shape
     unsigned long long xmax_bits, ymax_bits;             // bit patterns of MAGIC + (bound_w-1), MAGIC + (bound_h-1)
     int src_h, src_w, bound_h, bound_w, out_w;
     int row_begin, rows;                                 // produce output rows [row_begin, row_begin+rows)
     unsigned tiles_x, tiles_y, nblocks, cpx;
     unsigned tiles_x_magic, tiles_y_magic;               // floor(n/d) = umulhi(n, magic) for n < nblocks
-    int group;                                           // tools/warp_pipe_experiment.h only: patches per wave
+    int group;                                           // free parameter of a tools/warp_lab custom kernel
 };
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_as_longlong(v) >> 32); }
@@ -339,13 +339,22 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
 }
 
 
-// ---- 8 pixels per lane: one wave = a 128 x 4 output patch, one block = 4 waves stacked vertically (128 x 16) ----
+// ---- 8 pixels per lane: one wave = a 512-pixel output patch, one block = 4 waves = a 128 x 16 output tile ----------
 // Same arithmetic as warp_rgb8_fast, but the per-lane overhead (patch decode, coordinate setup, footprint,
-// staging set-up) is shared by twice as many pixels.
+// staging set-up) is shared by twice as many pixels, and the patch SHAPE is a template parameter:
+//
+//   LOG_PW = 7   128 x 4  patches, 4 stacked vertically      -- widest stores; footprint fits up to ~2 degrees of rotation
+//   LOG_PW = 6    64 x 8  patches, 2 x 2                     -- up to ~10 degrees
+//   LOG_PW = 5    32 x 16 patches, 4 side by side            -- any rotation at scale ~1
+//
+// The footprint capacity is an AREA, not a shape: a wave stages any footprint of `nrows` source rows x C 12-byte
+// chunks (4 texels each) with nrows * C <= F8_CHUNKS; the slab pitch is 16*C bytes, chosen by the wave at run time,
+// so chunk i of the row-major footprint simply lands at slab byte 16*i.  The host picks the widest shape whose
+// footprints fit (launch_fast); a wave whose footprint does not fit takes the gather path, so the choice only
+// affects speed, never the result.
 constexpr int F8_PX = 8;
-constexpr int F8_LANES = 21;                           // staging lanes per source row, 2 x 4 texels (2 x 12 B) each
-constexpr int F8_TEXELS = 8 * F8_LANES;                // 168 texels per staged row
-constexpr int F8_PITCH = 4 * F8_TEXELS + 16;           // 688 B per staged row
+constexpr int F8_PASSES = 6;                            // staging instructions per wave
+constexpr int F8_CHUNKS = 64 * F8_PASSES;               // 384 chunks = 1536 texels = 6 KB of RGBX per wave
 
 #ifndef RWH_F8_WAVES
 #define RWH_F8_WAVES 1
@@ -354,11 +363,14 @@ constexpr int F8_PITCH = 4 * F8_TEXELS + 16;           // 688 B per staged row
 // loads go out at once; the other six pixels are computed run by run (3 + 3, one batch inversion each) right before
 // their taps are read, so that only 4 pixels' coordinates, weights and taps are live at a time -- the kernel is
 // occupancy-sensitive (time ~ 9.5 + 35/n us per 4K frame for n resident waves per SIMD, n <= 5 measured) and this
-// keeps it at RWH_F8_WAVES waves.  The end pixels are computed once, so the footprint and the taps can never disagree
-// about a floor().
-template <typename DstT>
+// keeps it at 6 waves (LDS-limited).  The end pixels are computed once, so the footprint and the taps can never
+// disagree about a floor().
+template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastArgs a) {
-    __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * F8_PITCH];
+    constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
+    constexpr int LPR = PW / 8;                             // lanes per patch row
+    constexpr int WX = 128 / PW;                            // waves side by side in the block tile
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * F8_CHUNKS];
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
     const unsigned b = blockIdx.x;
@@ -370,17 +382,19 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     const unsigned ty = t - img * a.tiles_y;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
-    const int prow = lane >> 4, pq = lane & 15;               // patch row 0..3, 8-pixel column group 0..15
+    const int prow = lane / LPR, pq = lane % LPR;             // patch row, 4-pixel column group within a half row
+    const int wave_x = (wave % WX) * PW, wave_y = (wave / WX) * PH;   // patch origin inside the 128 x 16 tile
 
-    const int rr_raw = ((int)ty * 4 + wave) * 4 + prow;
+    const int rr_raw = (int)ty * 16 + wave_y + prow;
     const int rr = min(rr_raw, a.rows - 1);                   // rows past the shard recompute its last row
-    // a lane owns two runs of 4 pixels, 64 pixels apart: every store instruction then writes 16 lanes x 12 B = 192
+    // a lane owns two runs of 4 pixels, PW/2 pixels apart: every store instruction then writes LPR lanes x 12 B of
     // contiguous bytes per patch row (8 contiguous pixels per lane would leave 12-byte holes in every store).
     // A tile that sticks out of the row is moved left as a whole and owns only the columns >= its nominal start.
     const int tcol0 = (int)tx * 128;
     const int tcol = min(tcol0, a.out_w - 128);
     const int tshift = tcol0 - tcol;                          // uniform
-    const int c0p = tcol + pq * 4;
+    const int lcol = wave_x + pq * 4;                         // column inside the tile
+    const int c0p = tcol + lcol;
     const bool store_any = rr_raw < a.rows;
 
     const unsigned char* simg = a.src + (long long)img * a.src_img_stride;       // uniform
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         // W is affine along a row: positive at both ends of every lane's span <=> positive on the whole patch
         wpos = __all((int)((int)hi32(W0) > 0) & (int)((int)hi32(W7) > 0));
     }
-    // run h (0: pixels 0..3, 1: pixels 4..7 = columns +64..+67): the three pixels that are not an end pixel share
+    // run h (0: pixels 0..3, 1: pixels 4..7 = columns +PW/2 ..): the three pixels that are not an end pixel share
     // one reciprocal (batch inversion); registers are reused between the runs
     uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
     auto run_coords = [&](const int h) {
@@ -432,47 +446,44 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         hx[3 * h] = ehx[h]; lx[3 * h] = elx[h]; hy[3 * h] = ehy[h]; ly[3 * h] = ely[h];
     };
 
-    // ---- wave-uniform footprint from the four patch corners (lanes 0, 15, 48, 63), on the scalar unit ----
+    // ---- wave-uniform footprint from the four patch corners, on the scalar unit ----
     // hi dwords compare like the integers they encode (same exponent); out-of-range / NaN corners end up
     // as the min or the max and fail the range test below.
-    const int x0 = (int)__builtin_amdgcn_readlane(ehx[0], 0), x1 = (int)__builtin_amdgcn_readlane(ehx[1], 15);
-    const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 48), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
-    const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], 15);
-    const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 48), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
+    const int x0 = (int)__builtin_amdgcn_readlane(ehx[0], 0), x1 = (int)__builtin_amdgcn_readlane(ehx[1], LPR - 1);
+    const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
+    const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
     const int xa = min(x0, x1), xb = min(x2, x3), xc = max(x0, x1), xd = max(x2, x3);
     const int ya = min(y0, y1), yb = min(y2, y3), yc = max(y0, y1), yd = max(y2, y3);
     const int hxmn = __builtin_amdgcn_readfirstlane(min(xa, xb)), hxmx = __builtin_amdgcn_readfirstlane(max(xc, xd));
     const int hymn = __builtin_amdgcn_readfirstlane(min(ya, yb)), hymx = __builtin_amdgcn_readfirstlane(max(yc, yd));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
-    // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row,
-    // and the footprint (rows ymn..ymx+1, texels xmn..xmx+1) fits the slab
-    const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) &
-                        (ymx < min(a.bound_h - 1, a.src_h - 2)) & (ymx - ymn + 2 <= FP_ROWS) & (xmx - xmn + 2 <= F8_TEXELS);
+    // footprint: rows ymn..ymx+1, texels xmn..xmx+1, as nrows x C chunks of 4 texels
+    const int nrows = ymx - ymn + 2, C = (xmx - xmn + 5) >> 2;
+    const int total = nrows * C;
+    // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row (a chunk may read
+    // up to 9 bytes past the footprint's last texel: never past the row below), and the footprint fits the slab
+    const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
+                        (nrows <= F8_CHUNKS) & (C <= F8_CHUNKS / 4) & (total <= F8_CHUNKS);
 
-    // ---- staging loads go out now ----------------------------------------------------------------------------------
+    // ---- staging loads go out now: chunk i = lane + 64*p of the row-major footprint ------------------------------
     unsigned char* my = slab[wave];
-    // staging lane -> (source row srow of 3, texel group scol of 21): 24 packed bytes in, 8 RGBX texels out
-    const int srow = (lane * 49) >> 10;                     // lane / 21 for lane < 64
-    const int scol = lane - F8_LANES * srow;
-    // each row segment is read by two instructions of 21 lanes x 12 contiguous bytes (texels 0..83 and 84..167)
-    pk3 va[FP_ROWS / 3], vb[FP_ROWS / 3];
-    bool ona[FP_ROWS / 3], onb[FP_ROWS / 3];
+    pk3 v[F8_PASSES];
     if (staged) {
-        const int nrows = ymx - ymn + 2, ntex = xmx - xmn + 2;
         const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
-        const uint32_t goff = (uint32_t)srow * pitch + (uint32_t)scol * 12u;
-        const bool mine_a = (srow < 3) & (4 * scol < ntex), mine_b = (srow < 3) & (4 * scol + F8_TEXELS / 2 < ntex);
+        // row = i / C as (i * m) >> 16 with m = floor(2^16 / C) + 1: exact while i * (m*C - 2^16) < 2^16, and
+        // i < 384, m*C - 2^16 <= C <= 96
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f / (float)C)) + 1u;
 #pragma unroll
-        for (int k = 0; k < FP_ROWS / 3; ++k) {
-            ona[k] = mine_a & (3 * k + srow < nrows);
-            onb[k] = mine_b & (3 * k + srow < nrows);
-            va[k] = pk3{0u, 0u, 0u}; vb[k] = pk3{0u, 0u, 0u};
+        for (int p = 0; p < F8_PASSES; ++p) {
+            const uint32_t i = (uint32_t)(lane + 64 * p);
+            const uint32_t row = (i * m) >> 16, col = i - row * (uint32_t)C;
+            v[p] = pk3{0u, 0u, 0u};
 #ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
-            va[k] = pk3{goff, goff * 3u, goff * 5u}; vb[k] = pk3{goff * 7u, goff * 11u, goff * 13u};
+            v[p] = pk3{i, i * 3u, i * 5u};
 #else
-            if (ona[k]) __builtin_memcpy(&va[k], gbase + (size_t)(3 * k) * pitch + goff, 12);
-            if (onb[k]) __builtin_memcpy(&vb[k], gbase + (size_t)(3 * k) * pitch + goff + 3 * (F8_TEXELS / 2), 12);
+            if ((int)i < total) __builtin_memcpy(&v[p], gbase + (size_t)(row * pitch + col * 12u), 12);
 #endif
         }
     }
@@ -480,25 +491,17 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     uint32_t a0[FP_PX], b0[FP_PX], a1[FP_PX], b1[FP_PX];
     float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
     if (staged) {
-        unsigned char* wlds = my + srow * F8_PITCH + scol * 16;
-        const uint32_t lds_c = (uint32_t)hymn * (uint32_t)F8_PITCH + (uint32_t)hxmn * 4u;  // uniform
+        const uint32_t lpitch = 16u * (uint32_t)C;                                          // uniform slab pitch
+        const uint32_t lds_c = (uint32_t)hymn * lpitch + (uint32_t)hxmn * 4u;                // uniform
 #pragma unroll
-        for (int k = 0; k < FP_ROWS / 3; ++k) {
-            if (ona[k]) {                                       // 12 packed bytes -> 4 RGBX texels
+        for (int p = 0; p < F8_PASSES; ++p) {
+            if (lane + 64 * p < total) {                        // 12 packed bytes -> 4 RGBX texels
                 uint4 t4;
-                t4.x = va[k].a;
-                t4.y = __builtin_amdgcn_alignbyte(va[k].b, va[k].a, 3);
-                t4.z = __builtin_amdgcn_alignbyte(va[k].c, va[k].b, 2);
-                t4.w = va[k].c >> 8;
-                *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH) = t4;
-            }
-            if (onb[k]) {
-                uint4 t5;
-                t5.x = vb[k].a;
-                t5.y = __builtin_amdgcn_alignbyte(vb[k].b, vb[k].a, 3);
-                t5.z = __builtin_amdgcn_alignbyte(vb[k].c, vb[k].b, 2);
-                t5.w = vb[k].c >> 8;
-                *reinterpret_cast<uint4*>(wlds + 3 * k * F8_PITCH + 2 * F8_TEXELS) = t5;
+                t4.x = v[p].a;
+                t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
+                t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
+                t4.w = v[p].c >> 8;
+                *reinterpret_cast<uint4*>(my + 16 * (lane + 64 * p)) = t4;
             }
         }
         // the slab is wave-private: order this wave's LDS writes before its LDS reads, no block barrier
@@ -510,20 +513,19 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
             run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
-                const int q = j;
-                wx1[j] = (float)lx[q]; wx0[j] = (float)(~lx[q]);
-                wy1[j] = (float)ly[q] * W_SCALE; wy0[j] = (float)(~ly[q]) * W_SCALE;
-                const uint32_t lo = hy[q] * (uint32_t)F8_PITCH + hx[q] * 4u - lds_c;
+                wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
+                wy1[j] = (float)ly[j] * W_SCALE; wy0[j] = (float)(~ly[j]) * W_SCALE;
+                const uint32_t lo = hy[j] * lpitch + hx[j] * 4u - lds_c;
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
 #else
                 const uint32_t* t0 = reinterpret_cast<const uint32_t*>(my + lo);
-                a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t0[F8_PITCH / 4]; b1[j] = t0[F8_PITCH / 4 + 1];
+                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(my + lo + lpitch);
+                a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
 #endif
             }
-            // lane owns local pixels q >= shift; a half is stored whole when shift <= 4*h
-            const int first = tshift - (64 * h + 4 * pq);       // local pixels j >= first are this tile's
-            blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 192 * h, store_any & (first < 4), max(first, 0));
+            const int first = tshift - (lcol + (PW / 2) * h);   // local pixels j >= first are this tile's
+            blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h, store_any & (first < 4), max(first, 0));
         }
         return;
     }
@@ -536,15 +538,14 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         run_coords(h);
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j) {
-            const int q = j;
             // 0 <= s <= bound-1 on the bit patterns: positive doubles order like unsigned integers; negative
             // values and NaNs have patterns outside [MAGIC_BITS, xmax_bits]
-            const unsigned long long ubx = ((unsigned long long)hx[q] << 32) | lx[q], uby = ((unsigned long long)hy[q] << 32) | ly[q];
+            const unsigned long long ubx = ((unsigned long long)hx[j] << 32) | lx[j], uby = ((unsigned long long)hy[j] << 32) | ly[j];
             const bool valid = (ubx >= MAGIC_BITS) & (ubx <= a.xmax_bits) & (uby >= MAGIC_BITS) & (uby <= a.ymax_bits);
             const float sc = valid ? W_SCALE : 0.f;
-            const int ix = (int)(hx[q] - MAGIC_HI), iy = (int)(hy[q] - MAGIC_HI);
-            wx1[j] = (float)lx[q]; wx0[j] = (float)(~lx[q]);
-            wy1[j] = (float)ly[q] * sc; wy0[j] = (float)(~ly[q]) * sc;
+            const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
+            wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
+            wy1[j] = (float)ly[j] * sc; wy0[j] = (float)(~ly[j]) * sc;
             off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
             near_end |= valid & (iy > a.src_h - 3);
         }
@@ -568,9 +569,29 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
                 b1[j] = simg[o11] | (simg[o11 + 1] << 8) | (simg[o11 + 2] << 16);
             }
         }
-        const int first = tshift - (64 * h + 4 * pq);
-        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 192 * h, store_any & (first < 4), max(first, 0));
+        const int first = tshift - (lcol + (PW / 2) * h);
+        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h, store_any & (first < 4), max(first, 0));
     }
+}
+
+// Source footprint of a pw x ph output patch whose top-left pixel is (row r, column c) of the launch: chunks (12 B =
+// 4 texels, what the slab has to hold) and an estimate of the 128-byte lines its staging loads touch.  Host-side twin
+// of the kernel's footprint arithmetic, used only to choose the patch shape.  false: W <= 0 at a corner.
+inline bool patch_footprint(const FastArgs& a, double r, double c, int pw, int ph, long long* chunks, double* lines) {
+    double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
+    for (int k = 0; k < 4; ++k) {
+        const double rr = a.row_begin + r + (k & 2 ? ph - 1 : 0), cc = c + (k & 1 ? pw - 1 : 0);
+        const double X = a.cx[0] + rr * a.cx[1] + cc * a.cx[2], Y = a.cy[0] + rr * a.cy[1] + cc * a.cy[2];
+        const double W = a.cw[0] + rr * a.cw[1] + cc * a.cw[2];
+        if (!(W > 0)) return false;
+        const double x = __builtin_floor(X / W), y = __builtin_floor(Y / W);
+        xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax; ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
+    }
+    if (!(xmax - xmin < 1e6 && ymax - ymin < 1e6)) return false;
+    const long long nrows = (long long)(ymax - ymin) + 2, ntex = (long long)(xmax - xmin) + 2;
+    *chunks = nrows * ((ntex + 3) >> 2);
+    *lines = (double)nrows * (3.0 * (double)ntex / 128.0 + 1.0);
+    return true;
 }
 
 // floor(n / d) == umulhi(n, magic) for every n < n_max, or 0 if no such 32-bit magic exists

@@ -393,6 +393,44 @@ def test_warp_fallback_paths_vs_oracle(gpu, case):
     assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (case, int((d > 1).sum()), float((d != 0).mean()))
 
 
+@pytest.mark.parametrize("shape", ["7", "6", "5", None])
+@pytest.mark.parametrize("case", ["mild", "rot4", "rot12", "rot45", "rot89", "persp"])
+def test_warp_patch_shapes_vs_oracle(gpu, case, shape, monkeypatch):
+    """The 8 px kernel's three patch shapes (128x4 / 64x8 / 32x16, RWH_WARP_SHAPE forces one, None = the host's
+    choice) against the oracle on rotations that fit some shapes' slabs and not others, on a grid wider than one
+    tile with a ragged right edge and bottom (tile shift / row clamp)."""
+    from ransac_with_homography_amd import kernels
+    if shape is None:
+        monkeypatch.delenv("RWH_WARP_SHAPE", raising=False)
+    else:
+        monkeypatch.setenv("RWH_WARP_SHAPE", shape)
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (333, 517, 3), dtype=np.uint8)
+
+    def rot(deg, sc=1.0):
+        t = np.deg2rad(deg)
+        c, s, cx, cy = sc * np.cos(t), sc * np.sin(t), 258.0, 166.0
+        return np.array([[c, -s, cx - c * cx + s * cy], [s, c, cy - s * cx - c * cy], [0, 0, 1.0]])
+    H = {"mild": np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]]),
+         "rot4": rot(4), "rot12": rot(12, 1.07), "rot45": rot(45, 0.93), "rot89": rot(89.3),   # (exactly 90: integer coordinates on the last row make the reference itself index out of bounds)
+         "persp": np.array([[0.9, 0.2, 11.0], [-0.15, 1.1, 30.0], [3e-4, -2e-4, 1.0]])}[case]
+    inv = np.linalg.inv(H)
+    xs = np.linspace(-9, 540, 550)      # 550 columns: 4 full tiles + a 38-column ragged one
+    ys = np.linspace(-5, 345, 351)      # 351 rows: 21 full tile rows + 15
+    ref = _oracle_warp_on_grid(img, inv, xs, ys, (333, 517))
+    src = torch.from_numpy(img).to(gpu)
+    grid = kernels.Grid(-9, 540, 550, -5, 345, 351)
+    got = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.float32).cpu().numpy()
+    ok = close(got, ref)
+    assert (~ok).sum() <= 3, (case, shape, int((~ok).sum()), float(np.abs(got - ref).max()))
+    u8 = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8).cpu().numpy()
+    d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
+    assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (case, shape, int((d > 1).sum()), float((d != 0).mean()))
+    # row shards of the same launch reproduce it bit for bit (tile rows restart at the shard's first row)
+    part = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8, rows=(100, 229)).cpu().numpy()
+    assert np.array_equal(part, u8[100:229])
+
+
 # ------------------------------------------------------------------------------------------------
 # Exact mode (RWH_WARP_EXACT): bit-identical float64 / uint8 results
 # ------------------------------------------------------------------------------------------------

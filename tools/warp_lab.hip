@@ -39,6 +39,7 @@ __global__ void diff_count(const unsigned char* a, const unsigned char* b, size_
 // Memory-pattern twin of warp_rgb8_fast8: the same grid, the same staging-load and output-store instruction shapes
 // (6 source rows x 132 texels in, 4 rows x 128 px out per wave), LDS round trip, and ALU work replaced by NALU
 // dependent FMAs per lane.  Answers: what does this access pattern cost with no / with the real amount of arithmetic?
+constexpr int F8_PITCH = 688;   // the twin keeps the fixed 128 x 4 patch / 9 x 172 texel slab geometry
 template <int NALU, int MODE = 0>   // MODE 1: loads only, 2: stores only
 __global__ __launch_bounds__(256) void pattern_twin(const FastArgs a) {
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][FP_ROWS * F8_PITCH];
@@ -180,6 +181,9 @@ int main(int argc, char** argv) {
                                          G.y0 + G.h - 1, G.h, G.w, SH, SW, RWH_BILINEAR, dst, RWH_U8, (int64_t)G.w * G.h * 3, 0, G.h, RWH_WARP_EXACT, nullptr); }},
             {"fast u8 px4", [&] { return fast(0, 1); }},
             {"fast u8 px8", [&] { return fast(1, 1); }},
+            {"fast u8 px8 shape 128x4", [&] { setenv("RWH_WARP_SHAPE", "7", 1); int r = fast(1, 1); unsetenv("RWH_WARP_SHAPE"); return r; }},
+            {"fast u8 px8 shape 64x8", [&] { setenv("RWH_WARP_SHAPE", "6", 1); int r = fast(1, 1); unsetenv("RWH_WARP_SHAPE"); return r; }},
+            {"fast u8 px8 shape 32x16", [&] { setenv("RWH_WARP_SHAPE", "5", 1); int r = fast(1, 1); unsetenv("RWH_WARP_SHAPE"); return r; }},
             {"twin: px8 access pattern, no ALU", [&] { return fast(2, 0); }},
             {"twin: px8 access pattern + 220 FMA", [&] { return fast(2, 1); }},
             {"twin: px8 access pattern + 440 FMA", [&] { return fast(2, 2); }},
