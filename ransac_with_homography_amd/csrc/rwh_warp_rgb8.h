@@ -478,12 +478,12 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
 #pragma unroll
         for (int p = 0; p < F8_PASSES; ++p) {
             const uint32_t i = (uint32_t)(lane + 64 * p);
-            const uint32_t row = (i * m) >> 16, col = i - row * (uint32_t)C;
+            const uint32_t row = __umul24(i, m) >> 16, col = i - __umul24(row, (uint32_t)C);   // all factors < 2^24
             v[p] = pk3{0u, 0u, 0u};
 #ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
             v[p] = pk3{i, i * 3u, i * 5u};
 #else
-            if ((int)i < total) __builtin_memcpy(&v[p], gbase + (size_t)(row * pitch + col * 12u), 12);
+            if ((int)i < total) __builtin_memcpy(&v[p], gbase + (size_t)(__umul24(row, pitch) + __umul24(col, 12u)), 12);
 #endif
         }
     }
@@ -492,7 +492,6 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
     if (staged) {
         const uint32_t lpitch = 16u * (uint32_t)C;                                          // uniform slab pitch
-        const uint32_t lds_c = (uint32_t)hymn * lpitch + (uint32_t)hxmn * 4u;                // uniform
 #pragma unroll
         for (int p = 0; p < F8_PASSES; ++p) {
             if (lane + 64 * p < total) {                        // 12 packed bytes -> 4 RGBX texels
@@ -515,7 +514,8 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
             for (int j = 0; j < FP_PX; ++j) {
                 wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
                 wy1[j] = (float)ly[j] * W_SCALE; wy0[j] = (float)(~ly[j]) * W_SCALE;
-                const uint32_t lo = hy[j] * lpitch + hx[j] * 4u - lds_c;
+                // slab byte of tap (iy, ix): 24-bit multiply-add (full rate; a 32-bit v_mul_lo_u32 is quarter rate)
+                const uint32_t lo = __umul24(hy[j] - (uint32_t)hymn, lpitch) + ((hx[j] - (uint32_t)hxmn) << 2);
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
 #else
