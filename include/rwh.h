@@ -155,6 +155,33 @@ RWH_API int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m,
                       float* d_h, uint8_t* d_flags, int32_t* d_counts, uint64_t* d_masks, uint64_t* d_best,
                       int reset_best, void* stream);
 
+/* flag for rwh_ransac_batched */
+#define RWH_BATCH_DEVICE_SAMPLING 1u /* fill d_idx on the device (Philox4x32-10) instead of reading the caller's table */
+
+/*
+ * Many independent RANSAC searches in one submission (no counterpart in the reference,
+ * whose RANSAC.run handles one image pair per call, ransac.py:159-213): the loop of ransac.py:176-202 for P problems
+ * x K hypotheses each, as three launches (sampling, 4-point DLT, scorer) regardless of P.
+ *   d_pts_a, d_pts_b: the problems' correspondences concatenated, total x 2 float32;
+ *   d_offsets: P+1 int32, problem p owns rows d_offsets[p] .. d_offsets[p+1]-1; m_max >= the largest problem;
+ *   d_idx: P x K x 4 int32, indices LOCAL to each problem.  Without RWH_BATCH_DEVICE_SAMPLING the caller provides it
+ *     (e.g. numpy's stream, then every problem's result equals rwh_ransac_search on that table bit for bit); with the
+ *     flag the library fills it: Philox4x32-10, counter (hypothesis, problem, 0, 0), key = seed, four DISTINCT indices
+ *     per hypothesis by multiply-shift range reduction -- NOT the reference's sampler (ransac.py:177 draws with
+ *     replacement from numpy's legacy generator), a documented non-parity mode; problems with fewer than 4
+ *     correspondences get (0,0,0,0) and are flagged RWH_HYP_REPEATED;
+ *   d_need: P int32, per-problem early-exit count (ceil(M*d/100 + n), ransac.py:169);
+ *   d_h P*K x 9, d_flags P*K, d_counts P*K, d_masks P*K x ceil(m_max/64) (or NULL; words past a problem's own
+ *     ceil(M/64) are written as 0);
+ *   d_best: P x 2 uint64, reset here; per problem the two packed keys of rwh_score_count with the hypothesis index
+ *     counted inside the problem.
+ * Scoring arithmetic, tie-break and early-exit rules are those of rwh_score_count.
+ */
+RWH_API int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, const int32_t* d_offsets, int n_problems,
+                       int m_max, int k, int32_t* d_idx, uint64_t seed, double th, int loss,
+                       const int32_t* d_need, float* d_h, uint8_t* d_flags, int32_t* d_counts,
+                       uint64_t* d_masks, uint64_t* d_best, unsigned flags, void* stream);
+
 /*
  * Fused panorama compositor.  Replaces the body of stitchPanorama (homography.py:288-338) after its canvas
  * geometry (host, homography.py:303-321): addAlpha('Rate') + transformImageH + paste / alpha blend, in one pass

@@ -16,10 +16,11 @@ RWH_LOSS = {"fwd": 0, "backward": 1, "reproj": 2}
 RWH_WARP_ZERO_ORIGIN = 1
 RWH_WARP_EXACT = 2
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR = 1, 2
+RWH_BATCH_DEVICE_SAMPLING = 1
 
 # every symbol include/rwh.h declares (tests check the library exports them all)
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_warp_backward", "rwh_dlt4_batched",
-           "rwh_score_count", "rwh_project_points", "rwh_ransac_search", "rwh_stitch_panorama")
+           "rwh_score_count", "rwh_project_points", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama")
 
 
 class RwhUnavailable(RuntimeError):
@@ -52,6 +53,8 @@ def _bind(lib):
     lib.rwh_score_count.argtypes = [vp, vp, vp, i32, i32, f64, i32, i32, i64, vp, vp, vp, vp, vp]
     lib.rwh_ransac_search.restype = i32
     lib.rwh_ransac_search.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i64, vp, vp, vp, vp, vp, i32, vp]
+    lib.rwh_ransac_batched.restype = i32
+    lib.rwh_ransac_batched.argtypes = [vp, vp, vp, i32, i32, i32, vp, c.c_uint64, f64, i32, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.rwh_stitch_panorama.restype = i32
     lib.rwh_stitch_panorama.argtypes = [vp, i32, i32, vp, i32, i32, c.POINTER(f64), i32, i32, i32, i32,
                                         i32, i32, i32, i32, i32, i32, i32, f64, vp, u32, vp]

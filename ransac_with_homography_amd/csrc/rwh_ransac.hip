@@ -31,11 +31,20 @@ __device__ __forceinline__ void swap_if(bool c, double& a, double& b) {
     b = c ? t : b;
 }
 
+// Batched mode (rwh_ransac_batched): `offsets` != NULL; hypothesis t belongs to problem t / k_per, whose correspondences
+// are rows offsets[p] .. offsets[p+1]-1 of pa / pb, and idx holds indices local to the problem.
 __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int m,
                                                   const int32_t* __restrict__ idx, int k,
-                                                  float* __restrict__ hout, uint8_t* __restrict__ flags) {
+                                                  float* __restrict__ hout, uint8_t* __restrict__ flags,
+                                                  const int32_t* __restrict__ offsets, int k_per) {
     const int t = blockIdx.x * 64 + threadIdx.x;
     if (t >= k) return;
+    if (offsets) {
+        const int p = t / k_per;
+        const int base = offsets[p];
+        m = offsets[p + 1] - base;
+        pa += 2 * (size_t)base; pb += 2 * (size_t)base;
+    }
     int id[4];
     bool bad_index = false;
 #pragma unroll
@@ -124,6 +133,49 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// K0 (batched mode only): device sampling.  Philox4x32-10 (Salmon et al., SC'11), counter = (hypothesis index inside
+// the problem, problem index, 0, 0), key = the 64-bit seed: the samples of a problem depend on (seed, problem, hypothesis)
+// only.  The four 32-bit outputs become four DISTINCT indices in [0, m): j_i = mulhi(r_i, m - i) picks among the indices
+// not taken yet (multiply-shift range reduction: bias < m / 2^32).  NOT the reference's numpy.random stream
+// (ransac.py:177 samples with replacement from the legacy generator): a documented non-parity mode.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c[0]), lo0 = 0xD2511F53u * c[0];
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c[2]), lo1 = 0xCD9E8D57u * c[2];
+        const uint32_t n0 = hi1 ^ c[1] ^ k0, n2 = hi0 ^ c[3] ^ k1;
+        c[0] = n0; c[1] = lo1; c[2] = n2; c[3] = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+
+__global__ __launch_bounds__(256) void sample4_kernel(const int32_t* __restrict__ offsets, int n_problems, int k_per,
+                                                      unsigned long long seed, int32_t* __restrict__ idx) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_problems * k_per) return;
+    const int p = t / k_per, hyp = t - p * k_per;
+    const int m = offsets[p + 1] - offsets[p];
+    uint32_t c[4] = {(uint32_t)hyp, (uint32_t)p, 0u, 0u};
+    philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    int id[4] = {0, 0, 0, 0};
+    if (m >= 4) {
+        id[0] = (int)__umulhi(c[0], (uint32_t)m);
+        int j = (int)__umulhi(c[1], (uint32_t)(m - 1));
+        id[1] = j + (j >= id[0]);
+        int a = min(id[0], id[1]), b = max(id[0], id[1]);          // taken so far, ascending
+        j = (int)__umulhi(c[2], (uint32_t)(m - 2));
+        j += (j >= a); j += (j >= b);
+        id[2] = j;
+        int lo = min(a, j), hi = max(b, j), mid = a + b + j - lo - hi;
+        j = (int)__umulhi(c[3], (uint32_t)(m - 3));
+        j += (j >= lo); j += (j >= mid); j += (j >= hi);
+        id[3] = j;
+    }                                                               // m < 4: (0,0,0,0), flagged "repeated" by K1
+    reinterpret_cast<int4*>(idx)[t] = int4{id[0], id[1], id[2], id[3]};
+}
+
+// ------------------------------------------------------------------------------------------------
 // K2: one wavefront = one hypothesis, lanes stride over correspondences, ballot + popcount.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void proj(const float (&h)[9], float x, float y, float& px, float& py, float& pw) {
@@ -202,12 +254,29 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
                                                     const float* __restrict__ pb, int m, int k, int hpw, double th, int need,
                                                     long long hyp_base, int32_t* __restrict__ counts,
                                                     uint64_t* __restrict__ masks, unsigned long long* best,
-                                                    float* __restrict__ errs) {
+                                                    float* __restrict__ errs,
+                                                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ needs,
+                                                    int k_per, int mask_stride) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-    const int h_begin = wid * hpw;
-    if (h_begin >= k) return;
-    const int h_end = min(k, h_begin + hpw);
+    int h_begin, h_end;
+    if (offsets) {   // batched mode: a wave stays inside one problem; keys, need and hypothesis indices are per problem
+        const int wpp = (k_per + hpw - 1) / hpw;                     // waves per problem
+        const int p = wid / wpp, chunk = wid - p * wpp;
+        if ((long long)p * k_per >= k) return;
+        const int base = offsets[p];
+        m = offsets[p + 1] - base;
+        pa += 2 * (size_t)base; pb += 2 * (size_t)base;
+        need = needs[p];
+        best += 2 * p;
+        h_begin = p * k_per + chunk * hpw;
+        h_end = min((p + 1) * k_per, h_begin + hpw);
+        hyp_base = -(long long)p * k_per;                            // key index = hypothesis index inside the problem
+    } else {
+        h_begin = wid * hpw;
+        if (h_begin >= k) return;
+        h_end = min(k, h_begin + hpw);
+    }
     const int words = (m + 63) >> 6;
 
     float2 ra[WORDS > 0 ? WORDS : 1], rb[WORDS > 0 ? WORDS : 1];
@@ -239,12 +308,13 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
             }
             const unsigned long long bal = __ballot(inl);
             count += __popcll(bal);
-            if (masks && lane == 0) masks[(size_t)hyp * words + w] = bal;
+            if (masks && lane == 0) masks[(size_t)hyp * mask_stride + w] = bal;
         };
         if constexpr (WORDS > 0) {
 #pragma unroll
             for (int w = 0; w < WORDS; ++w)
                 if (w < words) score(w, ra[w], rb[w]);
+                else if (masks && w < mask_stride && lane == 0) masks[(size_t)hyp * mask_stride + w] = 0;   // batched: shorter problem
         } else {
             for (int w = 0; w < words; ++w) {
                 const int j = w * 64 + lane;
@@ -252,6 +322,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
                 const float2 b = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
                 score(w, a, b);
             }
+            if (masks && lane == 0)
+                for (int w = words; w < mask_stride; ++w) masks[(size_t)hyp * mask_stride + w] = 0;
         }
         if (lane == 0) counts[hyp] = count;
         const unsigned long long inv_idx = 0xFFFFFFFFull - (unsigned long long)(hyp_base + hyp);
@@ -299,7 +371,7 @@ extern "C" int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int 
     if (!d_pts_a || !d_pts_b || !d_idx || !d_h || !d_flags || m <= 0 || k < 0) return RWH_E_INVALID;
     if (k == 0) return RWH_OK;
     hipLaunchKernelGGL(dlt4_kernel, dim3((k + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), d_pts_a, d_pts_b,
-                       m, d_idx, k, d_h, d_flags);
+                       m, d_idx, k, d_h, d_flags, (const int32_t*)nullptr, 0);
     return check_launch();
 }
 
@@ -307,10 +379,12 @@ namespace rwh {
 template <int LOSS>
 void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
                   int hpw, double th, int need, long long hyp_base, int32_t* d_counts, uint64_t* d_masks,
-                  unsigned long long* best, float* d_err) {
+                  unsigned long long* best, float* d_err, const int32_t* offsets = nullptr, const int32_t* needs = nullptr,
+                  int k_per = 0, int mask_stride = -1) {
     const dim3 block(256);
+    if (mask_stride < 0) mask_stride = words;
 #define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, \
-                                        hyp_base, d_counts, d_masks, best, d_err)
+                                        hyp_base, d_counts, d_masks, best, d_err, offsets, needs, k_per, mask_stride)
     switch (words <= 4 ? words : 0) {
         case 1: RWH_SCORE(1); break;
         case 2: RWH_SCORE(2); break;
@@ -356,4 +430,38 @@ extern "C" int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int
     const int st = rwh_dlt4_batched(d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags, stream);
     if (st != RWH_OK) return st;
     return rwh_score_count(d_h, d_pts_a, d_pts_b, m, k, th, loss, need, hyp_base, d_counts, d_masks, d_best, nullptr, stream);
+}
+
+extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, const int32_t* d_offsets, int n_problems,
+                                  int m_max, int k, int32_t* d_idx, uint64_t seed, double th, int loss,
+                                  const int32_t* d_need, float* d_h, uint8_t* d_flags, int32_t* d_counts,
+                                  uint64_t* d_masks, uint64_t* d_best, unsigned flags, void* stream) {
+    using namespace rwh;
+    if (!d_pts_a || !d_pts_b || !d_offsets || !d_idx || !d_need || !d_h || !d_flags || !d_counts || !d_best) return RWH_E_INVALID;
+    if (n_problems < 0 || k < 0 || m_max <= 0) return RWH_E_INVALID;
+    if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ) return RWH_E_INVALID;
+    if (n_problems == 0 || k == 0) return RWH_OK;
+    const long long total = (long long)n_problems * k;
+    if (total >= (1ll << 31)) return RWH_E_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(d_best, 0, 16 * (size_t)n_problems, s) != hipSuccess) return RWH_E_LAUNCH;
+    if (flags & RWH_BATCH_DEVICE_SAMPLING)
+        hipLaunchKernelGGL(sample4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_offsets, n_problems, k,
+                           (unsigned long long)seed, d_idx);
+    hipLaunchKernelGGL(dlt4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, d_pts_a, d_pts_b, m_max, d_idx,
+                       (int)total, d_h, d_flags, d_offsets, k);
+    int hpw = (int)(total / (256 * 4 * 32));
+    hpw = hpw < 1 ? 1 : (hpw > 8 ? 8 : hpw);
+    if (hpw > k) hpw = k;
+    const long long waves = (long long)n_problems * ((k + hpw - 1) / hpw);
+    const dim3 grid((unsigned)((waves + 3) / 4));
+    const int words = (m_max + 63) / 64;
+    unsigned long long* best = reinterpret_cast<unsigned long long*>(d_best);
+    if (loss == RWH_LOSS_FWD)
+        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, 0, 0, d_counts, d_masks, best, nullptr, d_offsets, d_need, k, words);
+    else if (loss == RWH_LOSS_BACKWARD)
+        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, 0, 0, d_counts, d_masks, best, nullptr, d_offsets, d_need, k, words);
+    else
+        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, 0, 0, d_counts, d_masks, best, nullptr, d_offsets, d_need, k, words);
+    return check_launch();
 }

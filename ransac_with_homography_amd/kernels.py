@@ -136,6 +136,46 @@ def ransac_search(pts_a, pts_b, idx, th, loss, need, ws, hyp_base=0, reset_best=
     return ws
 
 
+class BatchWorkspace:
+    """Device buffers of one batched search: P problems x K hypotheses (rwh_ransac_batched)."""
+
+    def __init__(self, n_problems, k, m_max, device, want_masks=True):
+        self.p, self.k, self.m_max = n_problems, k, m_max
+        self.words = (m_max + 63) // 64
+        n = n_problems * k
+        self.idx = torch.empty((n_problems, k, 4), dtype=torch.int32, device=device)
+        self.H = torch.empty((n_problems, k, 9), dtype=torch.float32, device=device)
+        self.flags = torch.empty((n_problems, k), dtype=torch.uint8, device=device)
+        self.counts = torch.empty((n_problems, k), dtype=torch.int32, device=device)
+        self.masks = torch.empty((n_problems, k, self.words), dtype=torch.int64, device=device) if want_masks else None
+        self.best = torch.zeros((n_problems, 2), dtype=torch.int64, device=device)
+
+
+def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=None):
+    """P independent RANSAC searches in one library call (rwh_ransac_batched, include/rwh.h).
+
+    pts_a/pts_b: [total,2] float32 (the problems' correspondences concatenated), offsets: [P+1] int32,
+    needs: [P] int32 -- all on the GPU.  Either `idx` ([P,K,4] int32, problem-local indices, the caller's
+    sampler: parity with `ransac_search`) or `seed` (device Philox sampling, non-parity) must be given.
+    Results land in `ws` (ws.idx holds the samples actually used)."""
+    lib = _lib.load()
+    _dev_check(pts_a, pts_b, offsets, needs)
+    assert (seed is None) != (idx is None), "give exactly one of seed= (device sampling) and idx= (caller's samples)"
+    P = offsets.shape[0] - 1
+    assert P == ws.p and needs.shape[0] == P and offsets.dtype == torch.int32 and needs.dtype == torch.int32
+    flags = 0
+    if idx is None:
+        flags = _lib.RWH_BATCH_DEVICE_SAMPLING
+    else:
+        assert tuple(idx.shape) == (P, ws.k, 4) and idx.dtype == torch.int32
+        ws.idx.copy_(idx)
+    check(lib.rwh_ransac_batched(_ptr(pts_a), _ptr(pts_b), _ptr(offsets), P, ws.m_max, ws.k, _ptr(ws.idx),
+                                 int(seed or 0) & 0xFFFFFFFFFFFFFFFF, float(th), RWH_LOSS[loss], _ptr(needs), _ptr(ws.H),
+                                 _ptr(ws.flags), _ptr(ws.counts), _ptr(ws.masks) if ws.masks is not None else None,
+                                 _ptr(ws.best), flags, _lib.stream_ptr()), "rwh_ransac_batched")
+    return ws
+
+
 def project_points(h9, pts, inverse):
     """Launch the projection kernel: h9 [9] float32, pts [M,2] float32 -> [3,M] float32."""
     lib = _lib.load()

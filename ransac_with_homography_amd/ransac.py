@@ -196,6 +196,65 @@ class RANSAC(object):
         return finalModel, inliers, totalfit
 
 
+def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None):
+    """RANSAC over MANY image pairs in one GPU submission (the reference has no
+    counterpart: its RANSAC.run handles one pair per call, ransac.py:159-213).
+
+    datas: list of [X, Y] (each 2 x M_p or 3 x M_p, the `RANSAC.run` layout).  Returns a list of
+    `(finalModel float64 3x3, (inlier_indices,), count)` -- per problem exactly what `RANSAC.run` returns for the same
+    samples, including the final N-point refit on the host (ransac.py:206-211); `finalModel` is None for a problem
+    whose winner has too few inliers to refit (where `RANSAC.run` raises AssertionError).
+
+    Sampling: by default on the device (Philox4x32-10 keyed by `seed`, four distinct correspondences per hypothesis):
+    a documented NON-PARITY mode -- the reference draws with replacement from numpy's global legacy generator
+    (ransac.py:177).  Pass `idx` (list of [k,4] integer arrays, one per problem) to supply the samples yourself; each
+    problem's result then equals `RANSAC.run` on that table bit for bit.  The early-exit rule (ransac.py:186-190)
+    holds per problem either way: the first hypothesis whose count reaches M*d/100 + n wins."""
+    import torch
+    if method not in _lib.RWH_LOSS:
+        exit("Invalid method!")
+    if n != 4:
+        raise NotImplementedError("the homography model samples exactly 4 correspondences (ransac.py:270)")
+    dev = _lib.require_gpu()
+    P = len(datas)
+    if P == 0:
+        return []
+    sizes = []
+    for X, Y in datas:
+        assert X.shape[1] == Y.shape[1], "data observation not consistent!"
+        sizes.append(X.shape[1])
+    offsets = np.zeros(P + 1, dtype=np.int32)
+    offsets[1:] = np.cumsum(sizes)
+    pa = torch.from_numpy(np.concatenate([_points_rows(X) for X, _ in datas])).to(dev)
+    pb = torch.from_numpy(np.concatenate([_points_rows(Y) for _, Y in datas])).to(dev)
+    needs = torch.tensor([kernels.need_count(m, d, n) for m in sizes], dtype=torch.int32, device=dev)
+    ws = kernels.BatchWorkspace(P, int(k), max(max(sizes), 1), dev)
+    if idx is not None:
+        table = torch.from_numpy(np.stack([np.asarray(t).astype(np.int32) for t in idx])).to(dev)
+        kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, idx=table)
+    else:
+        kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed)
+    best = ws.best.cpu().numpy()
+    winners = [kernels.decode_best(best[p], int(k)) for p in range(P)]
+    rows = torch.tensor([[p, w[0] if w[0] is not None else 0] for p, w in enumerate(winners)], device=dev)
+    win_masks = ws.masks[rows[:, 0], rows[:, 1]].cpu().numpy()          # one gather, one copy for all problems
+    win_counts = ws.counts[rows[:, 0], rows[:, 1]].cpu().numpy()
+    out = []
+    for p, ((X, Y), (winner, _, early)) in enumerate(zip(datas, winners)):
+        model = HomoModel(th=th, d=d, n=n)
+        if winner is None or int(win_counts[p]) == 0:
+            inliers, total = (np.array([], dtype=np.int64),), 0
+        else:
+            bits = np.unpackbits(win_masks[p].view(np.uint8), bitorder="little")[:sizes[p]]
+            inliers, total = (np.nonzero(bits)[0].astype(np.int64),), np.int64(win_counts[p])
+        try:
+            H = model.fit(X[:, inliers[0]], Y[:, inliers[0]], collective=True)
+        except AssertionError:      # fewer inliers than a refit needs: RANSAC.run would raise here (ransac.py:38)
+            H = None
+        out.append((H, inliers, total))
+    return out
+
+
 def _match_features(trainImg, queryImg):
     """ORB + brute-force Hamming matcher of ransac.py:252-267.  This is OpenCV C++ and outside the
     GPU path; it runs only when cv2 is installed."""

@@ -279,6 +279,96 @@ def test_ransac_run_matches_reference_runs(gpu, matches):
         assert nxt == np.random.randint(0, 1 << 30), key
 
 
+def _batch_problems(matches):
+    """Five problems of different sizes cut from the 185 real correspondences (3 mask words down to 1; one with
+    exactly 4 points)."""
+    ptsA, ptsB = matches
+    rng = np.random.default_rng(11)
+    sets = [np.arange(185), np.sort(rng.choice(185, 130, replace=False)), np.sort(rng.choice(185, 64, replace=False)),
+            np.sort(rng.choice(185, 33, replace=False)), np.array([3, 50, 90, 140])]
+    return [[ptsA[i].T.copy(), ptsB[i].T.copy()] for i in sets]
+
+
+@pytest.mark.parametrize("method", ["fwd", "reproj"])
+def test_batched_search_equals_single_searches(gpu, matches, method):
+    """rwh_ransac_batched with the caller's index tables == one rwh_ransac_search per problem, bit for bit
+    (hypotheses, flags, counts, masks, packed keys), and run_batch(idx=) == RANSAC.run on the same numpy stream."""
+    import ransac as rs
+    from ransac_with_homography_amd import kernels
+    from ransac_with_homography_amd import ransac as rmod
+    probs = _batch_problems(matches)
+    K, th, d = 700, 5, 40
+    tables = []
+    for p, (X, _) in enumerate(probs):
+        np.random.seed(100 + p)
+        tables.append(np.random.randint(0, X.shape[1], (K, 4)))
+    sizes = [X.shape[1] for X, _ in probs]
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=gpu)
+    pa = torch.from_numpy(np.concatenate([np.ascontiguousarray(X.T[:, :2], np.float32) for X, _ in probs])).to(gpu)
+    pb = torch.from_numpy(np.concatenate([np.ascontiguousarray(Y.T[:, :2], np.float32) for _, Y in probs])).to(gpu)
+    needs = torch.tensor([kernels.need_count(m, d, 4) for m in sizes], dtype=torch.int32, device=gpu)
+    ws = kernels.BatchWorkspace(len(probs), K, max(sizes), gpu)
+    idx = torch.from_numpy(np.stack(tables).astype(np.int32)).to(gpu)
+    kernels.ransac_batched(pa, pb, offsets, needs, float(th), method, ws, idx=idx)
+    for p, m in enumerate(sizes):
+        o = int(offsets[p])
+        single = kernels.SearchWorkspace(K, m, gpu)
+        kernels.ransac_search(pa[o:o + m].contiguous(), pb[o:o + m].contiguous(), idx[p].contiguous(), float(th), method,
+                              kernels.need_count(m, d, 4), single)
+        assert torch.equal(ws.H[p].view(torch.int32), single.H.view(torch.int32)), p
+        assert torch.equal(ws.flags[p], single.flags) and torch.equal(ws.counts[p], single.counts), p
+        w = (m + 63) // 64
+        assert torch.equal(ws.masks[p][:, :w], single.masks) and not ws.masks[p][:, w:].any(), p
+        assert torch.equal(ws.best[p], single.best), p
+    got = rmod.run_batch(probs, th=th, d=d, k=K, method=method, idx=tables)
+    for p, (X, Y) in enumerate(probs):
+        np.random.seed(100 + p)
+        H, inl, cnt = rs.RANSAC(rs.HomoModel(th=th, d=d, n=4), k=K).run([X, Y], method=method)
+        assert int(got[p][2]) == int(cnt) and np.array_equal(got[p][1][0], inl[0]), p
+        assert np.array_equal(got[p][0], H), p
+
+
+def test_batched_device_sampling(gpu, matches):
+    """Device Philox sampling: the index table is the documented function of (seed, problem, hypothesis), the scores on
+    it are the oracle's, the result does not depend on what else is in the batch, and the early exit works per problem."""
+    from oracle import rwh_oracle as orc
+    from philox_ref import sample4
+    from ransac_with_homography_amd import kernels
+    from ransac_with_homography_amd import ransac as rmod
+    probs = _batch_problems(matches)
+    sizes = [X.shape[1] for X, _ in probs]
+    K, seed = 512, 0x1234567890ABCDEF
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=gpu)
+    pa = torch.from_numpy(np.concatenate([np.ascontiguousarray(X.T[:, :2], np.float32) for X, _ in probs])).to(gpu)
+    pb = torch.from_numpy(np.concatenate([np.ascontiguousarray(Y.T[:, :2], np.float32) for _, Y in probs])).to(gpu)
+    needs = torch.tensor([kernels.need_count(m, 70, 4) for m in sizes], dtype=torch.int32, device=gpu)
+    ws = kernels.BatchWorkspace(len(probs), K, max(sizes), gpu)
+    kernels.ransac_batched(pa, pb, offsets, needs, 5.0, "fwd", ws, seed=seed)
+    idx = ws.idx.cpu().numpy()
+    for p, m in enumerate(sizes):
+        assert np.array_equal(idx[p], sample4(seed, p, K, m)), p
+    # problem 0 (all 185 correspondences): the oracle's scores on the device-drawn samples
+    X, Y = probs[0]
+    Hs_ref, counts_ref = orc.ransac_table(X, Y, idx[0].astype(np.int64), th=5, method="fwd")
+    c = ws.counts[0].cpu().numpy()
+    same = np.all(ws.H[0].cpu().numpy().view(np.uint32) == Hs_ref.view(np.uint32), axis=1)
+    assert same.mean() > 0.97 and np.array_equal(c[same], counts_ref[same])
+    assert not (ws.flags[0].cpu().numpy() & 1).any()                  # distinct indices: never "repeated"
+    # the 4-point problem: every hypothesis is a permutation of its 4 points
+    assert (np.sort(idx[4], axis=1) == np.arange(4)).all()
+    # same seed, same problem index -> same result whatever follows it in the batch
+    ws2 = kernels.BatchWorkspace(2, K, max(sizes[:2]), gpu)
+    kernels.ransac_batched(pa[:sizes[0] + sizes[1]], pb[:sizes[0] + sizes[1]], offsets[:3].contiguous(), needs[:2].contiguous(),
+                           5.0, "fwd", ws2, seed=seed)
+    assert torch.equal(ws2.best, ws.best[:2]) and torch.equal(ws2.counts, ws.counts[:2])
+    # host wrapper: finds the panorama homography's inlier set size class on the full problem, early exit at d=40
+    res = rmod.run_batch(probs[:3], th=5, d=70, k=2000, method="fwd", seed=7)
+    assert 110 <= int(res[0][2]) <= 125 and res[0][0].shape == (3, 3) and res[0][0].dtype == np.float64
+    res40 = rmod.run_batch(probs[:3], th=5, d=40, k=2000, method="fwd", seed=7)
+    for (X, _), r in zip(probs[:3], res40):
+        assert int(r[2]) >= X.shape[1] * 40 / 100 + 4
+
+
 def test_model_helpers_match_oracle(gpu, matches):
     import ransac as rs
     from oracle import rwh_oracle as orc
