@@ -36,8 +36,12 @@ __device__ __forceinline__ void swap_if(bool c, double& a, double& b) {
 __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int m,
                                                   const int32_t* __restrict__ idx, int k,
                                                   float* __restrict__ hout, uint8_t* __restrict__ flags,
-                                                  const int32_t* __restrict__ offsets, int k_per) {
+                                                  const int32_t* __restrict__ offsets, int k_per,
+                                                  unsigned long long* __restrict__ reset_keys, int n_reset) {
     const int t = blockIdx.x * 64 + threadIdx.x;
+    // a search's packed argmax keys are cleared here instead of by a memset launch of their own (the grid always
+    // covers n_reset threads, see launch_dlt4)
+    if (reset_keys && t < n_reset) reset_keys[t] = 0ull;
     if (t >= k) return;
     if (offsets) {
         const int p = t / k_per;
@@ -247,31 +251,26 @@ __device__ __forceinline__ void inverse3(const float (&hf)[9], float (&inv)[9]) 
 
 // One wavefront scores HPW consecutive hypotheses.  WORDS > 0: the correspondences (M <= 64*WORDS) live in
 // registers for the whole wave -- lane l holds points l, l+64, ... -- so the loop over hypotheses is pure VALU +
-// scalar loads of H; WORDS == 0: any M, points streamed from L1/L2 per hypothesis.  The wave keeps its best packed
-// key in registers and issues at most one atomic per key word at the end.
+// scalar loads of H; WORDS == 0: any M, points streamed from L1/L2 per hypothesis.  Writes counts (and masks, losses);
+// the winner is picked from the counts by argmax_kernel.
 template <int LOSS, int WORDS>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs, const float* __restrict__ pa,
-                                                    const float* __restrict__ pb, int m, int k, int hpw, double th, int need,
-                                                    long long hyp_base, int32_t* __restrict__ counts,
-                                                    uint64_t* __restrict__ masks, unsigned long long* best,
-                                                    float* __restrict__ errs,
-                                                    const int32_t* __restrict__ offsets, const int32_t* __restrict__ needs,
+                                                    const float* __restrict__ pb, int m, int k, int hpw, double th,
+                                                    int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
+                                                    float* __restrict__ errs, const int32_t* __restrict__ offsets,
                                                     int k_per, int mask_stride) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int h_begin, h_end;
-    if (offsets) {   // batched mode: a wave stays inside one problem; keys, need and hypothesis indices are per problem
+    if (offsets) {   // batched mode: a wave stays inside one problem
         const int wpp = (k_per + hpw - 1) / hpw;                     // waves per problem
         const int p = wid / wpp, chunk = wid - p * wpp;
         if ((long long)p * k_per >= k) return;
         const int base = offsets[p];
         m = offsets[p + 1] - base;
         pa += 2 * (size_t)base; pb += 2 * (size_t)base;
-        need = needs[p];
-        best += 2 * p;
         h_begin = p * k_per + chunk * hpw;
         h_end = min((p + 1) * k_per, h_begin + hpw);
-        hyp_base = -(long long)p * k_per;                            // key index = hypothesis index inside the problem
     } else {
         h_begin = wid * hpw;
         if (h_begin >= k) return;
@@ -288,7 +287,6 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
             rb[w] = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
         }
     }
-    unsigned long long key0 = 0, key1 = 0;  // wave-local maxima of the two packed words
     for (int hyp = h_begin; hyp < h_end; ++hyp) {
         float h[9], hi[9];
 #pragma unroll
@@ -326,13 +324,46 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
                 for (int w = words; w < mask_stride; ++w) masks[(size_t)hyp * mask_stride + w] = 0;
         }
         if (lane == 0) counts[hyp] = count;
-        const unsigned long long inv_idx = 0xFFFFFFFFull - (unsigned long long)(hyp_base + hyp);
-        const unsigned long long key = ((unsigned long long)(unsigned)count << 32) | inv_idx;
-        key0 = key > key0 ? key : key0;
-        if (count >= need) key1 = inv_idx > key1 ? inv_idx : key1;
     }
-    if (lane == 0) {
-        // most waves lose against the running best: peek before paying for the atomic
+}
+
+// K2b: the accept rules of ransac.py:186-202 in their order-independent form, over the counts K2 wrote.
+//   word 0 = max over hypotheses of (count << 32) | (0xFFFFFFFF - index)      -> max count, lowest index on ties
+//   word 1 = max of 0xFFFFFFFF - index over hypotheses with count >= need     -> first index reaching `need`
+// One block reduces `chunk` hypotheses of one problem (blockIdx.y; k_per == 0: a single problem, indices offset by
+// hyp_base) and publishes with at most one atomic per word.  A separate pass because the alternative -- every wave of
+// K2 racing atomicMax on the same two words -- costs more than K2's arithmetic once the keys start at zero (+16 us at
+// K = 100 000: tools/batched_probe2.py).
+__global__ __launch_bounds__(256) void argmax_kernel(const int32_t* __restrict__ counts, int k, int k_per, int chunk, int need,
+                                                     const int32_t* __restrict__ needs, long long hyp_base,
+                                                     unsigned long long* best) {
+    __shared__ unsigned long long red[2][4];
+    const int p = blockIdx.y;
+    if (k_per) { counts += (size_t)p * k_per; k = k_per; need = needs[p]; best += 2 * p; hyp_base = 0; }
+    const int c0 = blockIdx.x * chunk, c1 = min(k, c0 + chunk);
+    unsigned long long key0 = 0, key1 = 0;
+    for (int i = c0 + (int)threadIdx.x; i < c1; i += 256) {
+        const int c = counts[i];
+        const unsigned long long inv_idx = 0xFFFFFFFFull - (unsigned long long)(hyp_base + i);
+        const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | inv_idx;
+        key0 = key > key0 ? key : key0;
+        if (c >= need) key1 = inv_idx > key1 ? inv_idx : key1;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long a = __shfl_xor(key0, o), b = __shfl_xor(key1, o);
+        key0 = a > key0 ? a : key0;
+        key1 = b > key1 ? b : key1;
+    }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][wave] = key0; red[1][wave] = key1; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            key0 = red[0][w] > key0 ? red[0][w] : key0;
+            key1 = red[1][w] > key1 ? red[1][w] : key1;
+        }
         if (key0 > __hip_atomic_load(&best[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[0], key0);
         if (key1 > __hip_atomic_load(&best[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(&best[1], key1);
     }
@@ -365,26 +396,42 @@ extern "C" int rwh_project_points(const float* d_h, const float* d_pts, int m, i
     return check_launch();
 }
 
+namespace rwh {
+static void launch_dlt4(hipStream_t s, const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k,
+                        float* d_h, uint8_t* d_flags, const int32_t* offsets, int k_per, unsigned long long* reset_keys,
+                        int n_reset) {
+    const int threads = k > n_reset ? k : n_reset;
+    hipLaunchKernelGGL(dlt4_kernel, dim3((threads + 63) / 64), dim3(64), 0, s, d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags,
+                       offsets, k_per, reset_keys, n_reset);
+}
+
+static void launch_argmax(hipStream_t s, const int32_t* d_counts, int k, int n_problems, int k_per, int need,
+                          const int32_t* needs, long long hyp_base, unsigned long long* best) {
+    const int per = k_per ? k_per : k;
+    const int chunk = per <= 2048 ? per : 2048;   // 8 counts per thread: the pass is latency-bound, not bandwidth-bound
+    hipLaunchKernelGGL(argmax_kernel, dim3((per + chunk - 1) / chunk, n_problems), dim3(256), 0, s, d_counts, k, k_per, chunk,
+                       need, needs, hyp_base, best);
+}
+}  // namespace rwh
+
 extern "C" int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k,
                                 float* d_h, uint8_t* d_flags, void* stream) {
     using namespace rwh;
     if (!d_pts_a || !d_pts_b || !d_idx || !d_h || !d_flags || m <= 0 || k < 0) return RWH_E_INVALID;
     if (k == 0) return RWH_OK;
-    hipLaunchKernelGGL(dlt4_kernel, dim3((k + 63) / 64), dim3(64), 0, static_cast<hipStream_t>(stream), d_pts_a, d_pts_b,
-                       m, d_idx, k, d_h, d_flags, (const int32_t*)nullptr, 0);
+    launch_dlt4(static_cast<hipStream_t>(stream), d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags, nullptr, 0, nullptr, 0);
     return check_launch();
 }
 
 namespace rwh {
 template <int LOSS>
 void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
-                  int hpw, double th, int need, long long hyp_base, int32_t* d_counts, uint64_t* d_masks,
-                  unsigned long long* best, float* d_err, const int32_t* offsets = nullptr, const int32_t* needs = nullptr,
-                  int k_per = 0, int mask_stride = -1) {
+                  int hpw, double th, int32_t* d_counts, uint64_t* d_masks, float* d_err,
+                  const int32_t* offsets = nullptr, int k_per = 0, int mask_stride = -1) {
     const dim3 block(256);
     if (mask_stride < 0) mask_stride = words;
-#define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, \
-                                        hyp_base, d_counts, d_masks, best, d_err, offsets, needs, k_per, mask_stride)
+#define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, \
+                                        d_counts, d_masks, d_err, offsets, k_per, mask_stride)
     switch (words <= 4 ? words : 0) {
         case 1: RWH_SCORE(1); break;
         case 2: RWH_SCORE(2); break;
@@ -412,22 +459,26 @@ extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const flo
     const int waves = (k + hpw - 1) / hpw;
     const dim3 grid((waves + 3) / 4);
     const int words = (m + 63) / 64;
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(d_best);
     if (loss == RWH_LOSS_FWD)
-        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, (long long)hyp_base, d_counts, d_masks, best, d_err);
+        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err);
     else if (loss == RWH_LOSS_BACKWARD)
-        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, (long long)hyp_base, d_counts, d_masks, best, d_err);
+        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err);
     else
-        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, need, (long long)hyp_base, d_counts, d_masks, best, d_err);
+        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err);
+    launch_argmax(s, d_counts, k, 1, 0, need, nullptr, (long long)hyp_base, reinterpret_cast<unsigned long long*>(d_best));
     return check_launch();
 }
 
 extern "C" int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k, double th,
                                  int loss, int need, int64_t hyp_base, float* d_h, uint8_t* d_flags, int32_t* d_counts,
                                  uint64_t* d_masks, uint64_t* d_best, int reset_best, void* stream) {
-    if (!d_best) return RWH_E_INVALID;
-    if (reset_best && hipMemsetAsync(d_best, 0, 16, static_cast<hipStream_t>(stream)) != hipSuccess) return RWH_E_LAUNCH;
-    const int st = rwh_dlt4_batched(d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags, stream);
+    using namespace rwh;
+    if (!d_best || !d_pts_a || !d_pts_b || !d_idx || !d_h || !d_flags || m <= 0 || k < 0) return RWH_E_INVALID;
+    // the DLT launch also clears the two keys (saves a memset launch per search)
+    if (k > 0 || reset_best)
+        launch_dlt4(static_cast<hipStream_t>(stream), d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags, nullptr, 0,
+                    reset_best ? reinterpret_cast<unsigned long long*>(d_best) : nullptr, reset_best ? 2 : 0);
+    const int st = check_launch();
     if (st != RWH_OK) return st;
     return rwh_score_count(d_h, d_pts_a, d_pts_b, m, k, th, loss, need, hyp_base, d_counts, d_masks, d_best, nullptr, stream);
 }
@@ -444,24 +495,23 @@ extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, co
     const long long total = (long long)n_problems * k;
     if (total >= (1ll << 31)) return RWH_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
-    if (hipMemsetAsync(d_best, 0, 16 * (size_t)n_problems, s) != hipSuccess) return RWH_E_LAUNCH;
     if (flags & RWH_BATCH_DEVICE_SAMPLING)
         hipLaunchKernelGGL(sample4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_offsets, n_problems, k,
                            (unsigned long long)seed, d_idx);
-    hipLaunchKernelGGL(dlt4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, s, d_pts_a, d_pts_b, m_max, d_idx,
-                       (int)total, d_h, d_flags, d_offsets, k);
+    launch_dlt4(s, d_pts_a, d_pts_b, m_max, d_idx, (int)total, d_h, d_flags, d_offsets, k,
+                reinterpret_cast<unsigned long long*>(d_best), 2 * n_problems);   // also clears the P x 2 keys
     int hpw = (int)(total / (256 * 4 * 32));
     hpw = hpw < 1 ? 1 : (hpw > 8 ? 8 : hpw);
     if (hpw > k) hpw = k;
     const long long waves = (long long)n_problems * ((k + hpw - 1) / hpw);
     const dim3 grid((unsigned)((waves + 3) / 4));
     const int words = (m_max + 63) / 64;
-    unsigned long long* best = reinterpret_cast<unsigned long long*>(d_best);
     if (loss == RWH_LOSS_FWD)
-        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, 0, 0, d_counts, d_masks, best, nullptr, d_offsets, d_need, k, words);
+        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words);
     else if (loss == RWH_LOSS_BACKWARD)
-        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, 0, 0, d_counts, d_masks, best, nullptr, d_offsets, d_need, k, words);
+        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words);
     else
-        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, 0, 0, d_counts, d_masks, best, nullptr, d_offsets, d_need, k, words);
+        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words);
+    launch_argmax(s, d_counts, (int)total, n_problems, k, 0, d_need, 0, reinterpret_cast<unsigned long long*>(d_best));
     return check_launch();
 }
