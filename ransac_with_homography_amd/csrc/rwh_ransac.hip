@@ -190,12 +190,15 @@ __device__ __forceinline__ void proj(const float (&h)[9], float x, float y, floa
     px = a0 / den; py = a1 / den; pw = a2 / den;  // IEEE: -fhip-fp32-correctly-rounded-divide-sqrt
 }
 
-__device__ __forceinline__ float proj_err(const float (&h)[9], float x, float y, float xp, float yp) {
+__device__ __forceinline__ float proj_sq(const float (&h)[9], float x, float y, float xp, float yp) {
     float px, py, pw;
     proj(h, x, y, px, py, pw);
     const float dx = px - xp, dy = py - yp;
-    const float s = dx * dx + dy * dy;
-    return sqrtf(s);  // correctly rounded (__fsqrt_rn would lower to the approximate native sqrt)
+    return dx * dx + dy * dy;
+}
+
+__device__ __forceinline__ float proj_err(const float (&h)[9], float x, float y, float xp, float yp) {
+    return sqrtf(proj_sq(h, x, y, xp, yp));  // correctly rounded (__fsqrt_rn would lower to the approximate native sqrt)
 }
 
 // float64 inverse of a float32 3x3 rounded back to float32 (numpy.linalg.inv on a float32 array,
@@ -256,7 +259,7 @@ __device__ __forceinline__ void inverse3(const float (&hf)[9], float (&inv)[9]) 
 template <int LOSS, int WORDS>
 __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs, const float* __restrict__ pa,
                                                     const float* __restrict__ pb, int m, int k, int hpw, double th,
-                                                    int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
+                                                    float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
                                                     float* __restrict__ errs, const int32_t* __restrict__ offsets,
                                                     int k_per, int mask_stride) {
     const int lane = threadIdx.x & 63;
@@ -297,12 +300,19 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
             const int j = w * 64 + lane;
             bool inl = false;
             if (j < m) {
-                float e;
-                if constexpr (LOSS == RWH_LOSS_FWD) e = proj_err(h, a.x, a.y, b.x, b.y);
-                else if constexpr (LOSS == RWH_LOSS_BACKWARD) e = proj_err(hi, b.x, b.y, a.x, a.y);
-                else { e = proj_err(h, a.x, a.y, b.x, b.y); e = e + proj_err(hi, b.x, b.y, a.x, a.y); }
-                inl = (double)e < th;
-                if (errs) errs[(size_t)hyp * m + j] = e;
+                if constexpr (LOSS == RWH_LOSS_REPROJ) {
+                    float e = proj_err(h, a.x, a.y, b.x, b.y);
+                    e = e + proj_err(hi, b.x, b.y, a.x, a.y);
+                    inl = (double)e < th;
+                    if (errs) errs[(size_t)hyp * m + j] = e;
+                } else {
+                    // one square root per pair: (double)sqrtf(s) < th  <=>  s < sq_limit, the smallest float whose
+                    // correctly rounded root reaches th (sqrtf is monotonic; found by the host, score_sq_limit) --
+                    // the same decision bit for bit without computing the root
+                    const float sq = LOSS == RWH_LOSS_FWD ? proj_sq(h, a.x, a.y, b.x, b.y) : proj_sq(hi, b.x, b.y, a.x, a.y);
+                    inl = sq < sq_limit;
+                    if (errs) errs[(size_t)hyp * m + j] = sqrtf(sq);
+                }
             }
             const unsigned long long bal = __ballot(inl);
             count += __popcll(bal);
@@ -424,14 +434,32 @@ extern "C" int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int 
 }
 
 namespace rwh {
+// Smallest non-negative float s with (double)sqrtf(s) >= th, so that "sqrtf(s) < th" == "s < limit" for every float s
+// (NaN compares false on both sides).  Bisection over the bit patterns of the non-negative floats, on which sqrtf --
+// correctly rounded here (glibc) and on the device (-fhip-fp32-correctly-rounded-divide-sqrt) -- is monotonic.
+static float score_sq_limit(double th) {
+    if (!(th > 0.0)) return 0.0f;                      // th <= 0 or NaN: nothing is ever < th
+    uint32_t lo = 0u, hi = 0x7f800000u;                // sqrtf(0) = 0 < th; sqrtf(inf) = inf is not < th (even for th = inf)
+    while (hi - lo > 1u) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        float f;
+        __builtin_memcpy(&f, &mid, 4);
+        if ((double)__builtin_sqrtf(f) < th) lo = mid; else hi = mid;
+    }
+    float f;
+    __builtin_memcpy(&f, &hi, 4);
+    return f;
+}
+
 template <int LOSS>
 void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
                   int hpw, double th, int32_t* d_counts, uint64_t* d_masks, float* d_err,
                   const int32_t* offsets = nullptr, int k_per = 0, int mask_stride = -1) {
     const dim3 block(256);
     if (mask_stride < 0) mask_stride = words;
+    const float sq_limit = score_sq_limit(th);
 #define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, \
-                                        d_counts, d_masks, d_err, offsets, k_per, mask_stride)
+                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride)
     switch (words <= 4 ? words : 0) {
         case 1: RWH_SCORE(1); break;
         case 2: RWH_SCORE(2); break;

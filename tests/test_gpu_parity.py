@@ -369,6 +369,37 @@ def test_batched_device_sampling(gpu, matches):
         assert int(r[2]) >= X.shape[1] * 40 / 100 + 4
 
 
+def test_scorer_threshold_edges(gpu):
+    """`err < th` is decided on the squared error against a host-computed limit (no square root per pair): the decision
+    must equal the oracle's `sqrt(...) < th` for thresholds sitting exactly on, one ulp below and one ulp above
+    attainable error values, as float32 and as float64 thresholds, and for degenerate thresholds."""
+    from oracle import rwh_oracle as orc
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(3)
+    M = 150
+    X = rng.uniform(0, 2000, (2, M)).astype(np.float32)
+    d = np.array([[3, 4], [1, 1], [0, 0], [5, 12], [0.5, 0.25], [1e-3, 2e-3], [300, 400]], dtype=np.float32)
+    Y = (X + d[rng.integers(0, len(d), M)].T).astype(np.float32)
+    Hs = np.stack([np.eye(3, dtype=np.float32).reshape(9),
+                   np.array([1.001, 2e-4, 0.5, -3e-4, 0.999, -0.25, 1e-7, -2e-7, 1], dtype=np.float32)])
+    pa = torch.from_numpy(np.ascontiguousarray(X.T)).to(gpu)
+    pb = torch.from_numpy(np.ascontiguousarray(Y.T)).to(gpu)
+    Hd = torch.from_numpy(Hs).to(gpu)
+    for method in ("fwd", "backward"):
+        errs = [orc.compute_loss(h.reshape(3, 3), X, Y, method) for h in Hs]
+        ths = [0.0, -1.0, float("inf"), float("nan"), 1e-30, 5, 5.0, np.float32(5.0), np.float64(np.nextafter(np.float32(5), np.float32(6))),
+               np.nextafter(5.0, 6.0), np.nextafter(5.0, 4.0)]
+        for e in np.unique(np.concatenate(errs))[::7]:
+            ths += [np.float64(e), np.nextafter(np.float64(e), np.inf), np.nextafter(np.float64(e), -np.inf)]
+        for th in ths:
+            best = kernels.new_best(gpu)
+            counts, masks, _ = kernels.score_count(Hd, pa, pb, float(th), method, 1 << 30, best)
+            for i, e in enumerate(errs):
+                want = e.astype(np.float64) < float(th)
+                bits = np.unpackbits(masks[i].cpu().numpy().view(np.uint8), bitorder="little")[:M].astype(bool)
+                assert np.array_equal(bits, want) and int(counts[i]) == int(want.sum()), (method, th, i)
+
+
 def test_model_helpers_match_oracle(gpu, matches):
     import ransac as rs
     from oracle import rwh_oracle as orc
