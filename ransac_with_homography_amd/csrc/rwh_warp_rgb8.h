@@ -218,8 +218,8 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
     unsigned long long ubx[FP_PX], uby[FP_PX];
 #pragma unroll
     for (int j = 0; j < FP_PX; ++j) {
-        const double ux = X[j] * rc[j] + MAGIC;
-        const double uy = Y[j] * rc[j] + MAGIC;
+        const double ux = fma(X[j], rc[j], MAGIC);   // one rounding, straight onto the 2^-32 grid
+        const double uy = fma(Y[j], rc[j], MAGIC);
         ubx[j] = (unsigned long long)__double_as_longlong(ux);
         uby[j] = (unsigned long long)__double_as_longlong(uy);
         lx[j] = lo32(ux); ly[j] = lo32(uy);
@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         const double X7 = X0 + a.dxs8[6][0], Y7 = Y0 + a.dxs8[6][1], W7 = W0 + a.dxs8[6][2];
         double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
         double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
-        const double ux0 = X0 * r0 + MAGIC, uy0 = Y0 * r0 + MAGIC, ux7 = X7 * r7 + MAGIC, uy7 = Y7 * r7 + MAGIC;
+        const double ux0 = fma(X0, r0, MAGIC), uy0 = fma(Y0, r0, MAGIC), ux7 = fma(X7, r7, MAGIC), uy7 = fma(Y7, r7, MAGIC);
         ehx[0] = hi32(ux0); elx[0] = lo32(ux0); ehy[0] = hi32(uy0); ely[0] = lo32(uy0);
         ehx[1] = hi32(ux7); elx[1] = lo32(ux7); ehy[1] = hi32(uy7); ely[1] = lo32(uy7);
         // W is affine along a row: positive at both ends of every lane's span <=> positive on the whole patch
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         }
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const double ux = X[j] * rc[j] + MAGIC, uy = Y[j] * rc[j] + MAGIC;
+            const double ux = fma(X[j], rc[j], MAGIC), uy = fma(Y[j], rc[j], MAGIC);   // one rounding, onto the 2^-32 grid
             const int q = j + 1 - h;
             hx[q] = hi32(ux); lx[q] = lo32(ux); hy[q] = hi32(uy); ly[q] = lo32(uy);
         }
