@@ -320,17 +320,19 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 }
 
 // Patch shape of the 8 px kernel (log2 of the patch width: 7, 6 or 5).  Over a 5 x 5 sample of patch positions, a shape
-// qualifies if its source footprints fit the LDS slab (nearly) everywhere; among those the one whose staging loads touch
-// the fewest 128-byte lines wins (a 128 x 4 patch rotated by 90 degrees "fits", but as 130 rows of 6 texels), the wider
-// shape on a near tie (longer contiguous stores).  RWH_WARP_SHAPE=5|6|7 in the environment overrides (tests, lab).
+// qualifies if its source footprints fit the LDS slab (nearly) everywhere.  64 x 8 is the default (measured 2-3 % ahead
+// of 128 x 4 on axis-aligned warps: fewer staged chunks per pixel); another qualifying shape replaces it only if its
+// staging loads touch clearly fewer 128-byte lines (a 64 x 8 patch rotated by 90 degrees "fits", but as 66 rows of 10
+// texels).  RWH_WARP_SHAPE=5|6|7 in the environment overrides (tests, lab).
 static int choose_shape(const FastArgs& a) {
     if (const char* e = getenv("RWH_WARP_SHAPE")) {
         const int v = atoi(e);
         if (v >= 5 && v <= 7) return v;
     }
-    int best = 7;
+    int best = 0;
     double best_lines = 1e300;
-    for (int lp = 7; lp >= 5; --lp) {
+    const int order[3] = {6, 7, 5};
+    for (int lp : order) {
         const int pw = 1 << lp, ph = 512 >> lp;
         int seen = 0, fit = 0;
         double lines_sum = 0;
@@ -341,11 +343,11 @@ static int choose_shape(const FastArgs& a) {
                 if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &ch, &ln)) continue;   // horizon: gathers anyway
                 ++seen; fit += ch <= F8_CHUNKS; lines_sum += ln;
             }
-        if (seen == 0) return 7;
+        if (seen == 0) return 6;
         if (10 * fit < 9 * seen) continue;
-        if (lines_sum < 0.95 * best_lines) { best = lp; best_lines = lines_sum; }
+        if (!best || lines_sum < 0.85 * best_lines) { best = lp; best_lines = lines_sum; }
     }
-    return best;   // nothing fits (strong zoom-out): every wave gathers; 7 has the longest stores
+    return best ? best : 7;   // nothing fits (strong zoom-out): every wave gathers; 128 x 4 has the longest stores
 }
 
 // Fast-path launch (RGB u8, bilinear): returns RWH_E_UNSUPPORTED when the shape needs the generic kernel.

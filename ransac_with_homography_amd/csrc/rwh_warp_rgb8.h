@@ -67,6 +67,19 @@ __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)__double_as_longlong(v); }
 __device__ __forceinline__ float ubyte(uint32_t v, int byte) { return (float)((v >> (8 * byte)) & 0xffu); }
 
+constexpr float W_ONE = 2.3283064365386963e-10f;      // 2^-32 = the y weights' "1.0" after the 2^-64 scale
+
+// Bilinear weights of one pixel from the low dwords of its magic-number coordinates (fraction * 2^32):
+// wx1 = frac_x * 2^32, wx0 = 2^32 - wx1 (Sterbenz-exact or rounded once, like a convert of the complement would be);
+// wy1 = frac_y * 2^-32, wy0 = 2^-32 - wy1 in one fused step.  sc / one = (2^-64, 2^-32), or (0, 0) for a masked pixel.
+__device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, float one, float& wx0, float& wx1, float& wy0, float& wy1) {
+    wx1 = (float)lx;
+    wx0 = 4294967296.0f - wx1;
+    const float fy = (float)ly;
+    wy1 = fy * sc;
+    wy0 = __builtin_fmaf(-fy, sc, one);
+}
+
 // Blend 4 pixels (taps a0 = texel(iy,ix), b0 = texel(iy,ix+1), a1/b1 = row iy+1; R,G,B in bytes 0..2)
 // and store them.  `full`: the lane owns all 4 pixels; otherwise it owns local pixels j >= shift.
 template <typename DstT>
@@ -474,17 +487,21 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
         // row = i / C as (i * m) >> 16 with m = floor(2^16 / C) + 1: exact while i * (m*C - 2^16) < 2^16, and
         // i < 384, m*C - 2^16 <= C <= 96
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f / (float)C)) + 1u;
+        // (v_rcp_f32 is good to 1 ulp: the quotient's error, < 2^16/C * 2^-22, stays below its distance 1/C from the
+        // next integer -- or the quotient is an exact power of two -- so the floor is the exact one)
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f * __builtin_amdgcn_rcpf((float)C))) + 1u;
 #pragma unroll
         for (int p = 0; p < F8_PASSES; ++p) {
-            const uint32_t i = (uint32_t)(lane + 64 * p);
-            const uint32_t row = __umul24(i, m) >> 16, col = i - __umul24(row, (uint32_t)C);   // all factors < 2^24
             v[p] = pk3{0u, 0u, 0u};
+            if (64 * p < total) {                                   // uniform: unused passes cost nothing
+                const uint32_t i = (uint32_t)(lane + 64 * p);
+                const uint32_t row = __umul24(i, m) >> 16, col = i - __umul24(row, (uint32_t)C);   // all factors < 2^24
 #ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
-            v[p] = pk3{i, i * 3u, i * 5u};
+                v[p] = pk3{i, i * 3u, i * 5u};
 #else
-            if ((int)i < total) __builtin_memcpy(&v[p], gbase + (size_t)(__umul24(row, pitch) + __umul24(col, 12u)), 12);
+                if ((int)i < total) __builtin_memcpy(&v[p], gbase + (size_t)(__umul24(row, pitch) + __umul24(col, 12u)), 12);
 #endif
+            }
         }
     }
 
@@ -492,9 +509,16 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
     if (staged) {
         const uint32_t lpitch = 16u * (uint32_t)C;                                          // uniform slab pitch
+        // slab byte of tap (iy, ix) = (iy - ymn) * lpitch + (ix - xmn) * 4, straight from the hi dwords: the 24-bit
+        // multiply sees hy & 0xFFFFFF = 0x380000 + iy, the shift drops the exponent bits of hx; both constants, the
+        // footprint origin and the slab's own LDS offset go into one uniform
+        // (the multiply-add is spelled in assembly: given __umul24, LLVM distributes the subtraction and emits a
+        //  quarter-rate v_mul_lo_u32 per tap)
+        const uint32_t slab_off = (uint32_t)wave * (16u * F8_CHUNKS);
+        const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;   // uniform
 #pragma unroll
         for (int p = 0; p < F8_PASSES; ++p) {
-            if (lane + 64 * p < total) {                        // 12 packed bytes -> 4 RGBX texels
+            if (64 * p < total && lane + 64 * p < total) {      // 12 packed bytes -> 4 RGBX texels
                 uint4 t4;
                 t4.x = v[p].a;
                 t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
@@ -512,15 +536,14 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
             run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
-                wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
-                wy1[j] = (float)ly[j] * W_SCALE; wy0[j] = (float)(~ly[j]) * W_SCALE;
-                // slab byte of tap (iy, ix): 24-bit multiply-add (full rate; a 32-bit v_mul_lo_u32 is quarter rate)
-                const uint32_t lo = __umul24(hy[j] - (uint32_t)hymn, lpitch) + ((hx[j] - (uint32_t)hxmn) << 2);
+                weights(lx[j], ly[j], W_SCALE, W_ONE, wx0[j], wx1[j], wy0[j], wy1[j]);
+                uint32_t lo;
+                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lo) : "v"(hy[j]), "s"(lpitch), "v"((hx[j] << 2) - tap_c));
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
 #else
-                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(my + lo);
-                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(my + lo + lpitch);
+                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo);
+                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo + lpitch);
                 a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
 #endif
             }
@@ -542,10 +565,8 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
             // values and NaNs have patterns outside [MAGIC_BITS, xmax_bits]
             const unsigned long long ubx = ((unsigned long long)hx[j] << 32) | lx[j], uby = ((unsigned long long)hy[j] << 32) | ly[j];
             const bool valid = (ubx >= MAGIC_BITS) & (ubx <= a.xmax_bits) & (uby >= MAGIC_BITS) & (uby <= a.ymax_bits);
-            const float sc = valid ? W_SCALE : 0.f;
             const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
-            wx1[j] = (float)lx[j]; wx0[j] = (float)(~lx[j]);
-            wy1[j] = (float)ly[j] * sc; wy0[j] = (float)(~ly[j]) * sc;
+            weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
             off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
             near_end |= valid & (iy > a.src_h - 3);
         }
