@@ -29,6 +29,7 @@ sys.path.insert(0, ROOT)
 H_S = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
 SRC_H, SRC_W = 2160, 3840
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec peak
+PREWARM_MS = 150.0    # untimed clock ramp before the warm-up steps (see main)
 
 
 def cpu_baseline(frames_note):
@@ -126,6 +127,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Clock ramp: an idle MI355X needs tens of milliseconds of work before it runs at its sustained clocks (measured:
+    # 0.60 ms per step in the first 10 steps after the Python set-up, 0.49 ms from ~50 steps on).  Keep the GPU busy for
+    # PREWARM_MS first, untimed like the warm-up steps, so that K timed steps measure the steady state whatever K is.
+    t_ramp = time.perf_counter()
+    while (time.perf_counter() - t_ramp) * 1e3 < PREWARM_MS:
+        for _ in range(10):
+            step()
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()
     sync_all()
@@ -226,7 +235,8 @@ def main():
             "vs_baseline": None, "dtype": "u8 (f64 coordinates, f32 blend)", "data": "synthetic",
             "config": {"workload": "transformImageH warp %dx%d RGB u8 bilinear -> %dx%d u8, %d distinct frames per "
                                    "GPU per step, Hs mild perspective" % (SRC_W, SRC_H, out_h, out_w, B),
-                       "frames_per_step_per_gpu": B, "sharding": "by image, no collective"},
+                       "frames_per_step_per_gpu": B, "sharding": "by image, no collective",
+                       "untimed_clock_ramp_ms": PREWARM_MS},
             "roofline": {"bound": "hbm", "kernel": "rwh::warp_rgb8_fast8<unsigned char, 6>", "achieved": round(achieved, 1),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,

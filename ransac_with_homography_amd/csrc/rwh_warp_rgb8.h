@@ -67,6 +67,29 @@ __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_
 __device__ __forceinline__ uint32_t lo32(double v) { return (uint32_t)__double_as_longlong(v); }
 __device__ __forceinline__ float ubyte(uint32_t v, int byte) { return (float)((v >> (8 * byte)) & 0xffu); }
 
+// 24-bit multiplies spelled in assembly: LLVM rewrites __umul24 of provably small operands into the quarter-rate
+// 32-bit v_mul_lo_u32.
+__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t mul24_s(uint32_t a, uint32_t b_uniform) {      // b in an SGPR
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint32_t c) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
+    return r;
+}
+__device__ __forceinline__ uint32_t mul24_12(uint32_t a) {                          // inline constant
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, 12" : "=v"(r) : "v"(a));
+    return r;
+}
+
 constexpr float W_ONE = 2.3283064365386963e-10f;      // 2^-32 = the y weights' "1.0" after the 2^-64 scale
 
 // Bilinear weights of one pixel from the low dwords of its magic-number coordinates (fraction * 2^32):
@@ -490,16 +513,17 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         // (v_rcp_f32 is good to 1 ulp: the quotient's error, < 2^16/C * 2^-22, stays below its distance 1/C from the
         // next integer -- or the quotient is an exact power of two -- so the floor is the exact one)
         const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f * __builtin_amdgcn_rcpf((float)C))) + 1u;
+        const uint32_t last = (uint32_t)total - 1u;
 #pragma unroll
         for (int p = 0; p < F8_PASSES; ++p) {
-            v[p] = pk3{0u, 0u, 0u};
             if (64 * p < total) {                                   // uniform: unused passes cost nothing
-                const uint32_t i = (uint32_t)(lane + 64 * p);
-                const uint32_t row = __umul24(i, m) >> 16, col = i - __umul24(row, (uint32_t)C);   // all factors < 2^24
+                // lanes past the footprint's last chunk re-read it (no exec masking, nothing stored for them)
+                const uint32_t i = min((uint32_t)(lane + 64 * p), last);
+                const uint32_t row = mul24(i, m) >> 16, col = i - mul24_s(row, (uint32_t)C);   // all factors < 2^24
 #ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
                 v[p] = pk3{i, i * 3u, i * 5u};
 #else
-                if ((int)i < total) __builtin_memcpy(&v[p], gbase + (size_t)(__umul24(row, pitch) + __umul24(col, 12u)), 12);
+                __builtin_memcpy(&v[p], gbase + (size_t)mad24_s(row, pitch, mul24_12(col)), 12);
 #endif
             }
         }
@@ -537,8 +561,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 weights(lx[j], ly[j], W_SCALE, W_ONE, wx0[j], wx1[j], wy0[j], wy1[j]);
-                uint32_t lo;
-                asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(lo) : "v"(hy[j]), "s"(lpitch), "v"((hx[j] << 2) - tap_c));
+                const uint32_t lo = mad24_s(hy[j], lpitch, (hx[j] << 2) - tap_c);
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
 #else

@@ -198,7 +198,7 @@ int main(int argc, char** argv) {
             CK(hipMemset(dst, 0, nbytes));
             for (int i = 0; i < 2; ++i) if (c.run() != 0) { printf("launch failed\n"); return 1; }
             CK(hipEventRecord(e0));
-            const int reps = 10;
+            const int reps = getenv("LAB_REPS") ? atoi(getenv("LAB_REPS")) : 10;
             for (int i = 0; i < reps; ++i) c.run();
             CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
