@@ -453,8 +453,11 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         const double ux0 = fma(X0, r0, MAGIC), uy0 = fma(Y0, r0, MAGIC), ux7 = fma(X7, r7, MAGIC), uy7 = fma(Y7, r7, MAGIC);
         ehx[0] = hi32(ux0); elx[0] = lo32(ux0); ehy[0] = hi32(uy0); ely[0] = lo32(uy0);
         ehx[1] = hi32(ux7); elx[1] = lo32(ux7); ehy[1] = hi32(uy7); ely[1] = lo32(uy7);
-        // W is affine along a row: positive at both ends of every lane's span <=> positive on the whole patch
-        wpos = __all((int)((int)hi32(W0) > 0) & (int)((int)hi32(W7) > 0));
+        // W is affine along a row: positive at both ends of every lane's span <=> positive on the whole patch.
+        // Magnitudes inside [2^-300, 2^300] at both ends as well: then the product of three W of a run is a finite
+        // normal number, and the batch inversion below needs no per-run check.
+        const int h0 = (int)hi32(W0), h7 = (int)hi32(W7);
+        wpos = __all((int)(h0 > 0x2D300000) & (int)(h0 < 0x52B00000) & (int)(h7 > 0x2D300000) & (int)(h7 < 0x52B00000));
     }
     // run h (0: pixels 0..3, 1: pixels 4..7 = columns +PW/2 ..): the three pixels that are not an end pixel share
     // one reciprocal (batch inversion); registers are reused between the runs
@@ -464,7 +467,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
 #pragma unroll
         for (int j = 0; j < 3; ++j) { X[j] = X0 + a.dxs8[3 * h + j][0]; Y[j] = Y0 + a.dxs8[3 * h + j][1]; W[j] = W0 + a.dxs8[3 * h + j][2]; }
         const double p12 = W[0] * W[1], P = p12 * W[2];
-        if (wpos & (bool)__all((int)__builtin_amdgcn_class(P, 0x100))) {   // finite, normal product of positive W
+        if (wpos) {                                                        // finite, normal product of positive W
             double rp = __builtin_amdgcn_rcp(P);
             rp = fma(fma(-P, rp, 1.0), rp, rp);
             const double r12 = rp * W[2];
