@@ -132,6 +132,8 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
     const double rw = fma(a.ih[7], y, a.ih[8]);
     const double bw1 = (double)(a.bound_w - 1), bh1 = (double)(a.bound_h - 1);
 
+    const bool whole = c0 + PX <= a.out_w;   // the lane's PX pixels are all inside the row: one vector store at the end
+    DstT packed[PX * C];
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int c = c0 + j;
@@ -175,9 +177,17 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
                 for (int k = 0; k < C; ++k) o[k] = 0.f;
             }
         }
+        if (whole) {
 #pragma unroll
-        for (int k = 0; k < C; ++k) drow[j * C + k] = to_dst<DstT>(o[k]);
+            for (int k = 0; k < C; ++k) packed[j * C + k] = to_dst<DstT>(o[k]);
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) drow[j * C + k] = to_dst<DstT>(o[k]);
+        }
     }
+    // PX*C elements = 12 / 16 bytes (u8) or 48 / 64 bytes (f32) per lane in one go instead of PX*C scalar stores
+    // (a 64-lane byte store costs the texture-address unit as much as a 64-lane dword store)
+    if (whole) __builtin_memcpy(drow, packed, sizeof(packed));
 }
 
 template <typename K> int launch(K kernel, const WarpArgs& a, hipStream_t s);
