@@ -166,7 +166,9 @@ RWH_API int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m,
  *   d_offsets: P+1 int32, problem p owns rows d_offsets[p] .. d_offsets[p+1]-1; m_max >= the largest problem;
  *   d_idx: P x K x 4 int32, indices LOCAL to each problem.  Without RWH_BATCH_DEVICE_SAMPLING the caller provides it
  *     (e.g. numpy's stream, then every problem's result equals rwh_ransac_search on that table bit for bit); with the
- *     flag the library fills it: Philox4x32-10, counter (hypothesis, problem, 0, 0), key = seed, four DISTINCT indices
+ *     flag the library fills it: Philox4x32-10, counter (hypothesis, problem_base + problem, 0, 0) -- `problem_base` is
+ *     the global index of this call's first problem, so that a problem list sharded over several calls / GPUs draws
+ *     the tables of the unsharded run --, key = seed, four DISTINCT indices
  *     per hypothesis by multiply-shift range reduction -- NOT the reference's sampler (ransac.py:177 draws with
  *     replacement from numpy's legacy generator), a documented non-parity mode; problems with fewer than 4
  *     correspondences get (0,0,0,0) and are flagged RWH_HYP_REPEATED;
@@ -178,7 +180,7 @@ RWH_API int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m,
  * Scoring arithmetic, tie-break and early-exit rules are those of rwh_score_count.
  */
 RWH_API int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, const int32_t* d_offsets, int n_problems,
-                       int m_max, int k, int32_t* d_idx, uint64_t seed, double th, int loss,
+                       int m_max, int k, int32_t* d_idx, uint64_t seed, int64_t problem_base, double th, int loss,
                        const int32_t* d_need, float* d_h, uint8_t* d_flags, int32_t* d_counts,
                        uint64_t* d_masks, uint64_t* d_best, unsigned flags, void* stream);
 

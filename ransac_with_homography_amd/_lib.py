@@ -54,7 +54,7 @@ def _bind(lib):
     lib.rwh_ransac_search.restype = i32
     lib.rwh_ransac_search.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i64, vp, vp, vp, vp, vp, i32, vp]
     lib.rwh_ransac_batched.restype = i32
-    lib.rwh_ransac_batched.argtypes = [vp, vp, vp, i32, i32, i32, vp, c.c_uint64, f64, i32, vp, vp, vp, vp, vp, vp, u32, vp]
+    lib.rwh_ransac_batched.argtypes = [vp, vp, vp, i32, i32, i32, vp, c.c_uint64, i64, f64, i32, vp, vp, vp, vp, vp, vp, u32, vp]
     lib.rwh_stitch_panorama.restype = i32
     lib.rwh_stitch_panorama.argtypes = [vp, i32, i32, vp, i32, i32, c.POINTER(f64), i32, i32, i32, i32,
                                         i32, i32, i32, i32, i32, i32, i32, f64, vp, u32, vp]

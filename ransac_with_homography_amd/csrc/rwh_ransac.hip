@@ -155,12 +155,13 @@ __device__ __forceinline__ void philox4x32_10(uint32_t (&c)[4], uint32_t k0, uin
 }
 
 __global__ __launch_bounds__(256) void sample4_kernel(const int32_t* __restrict__ offsets, int n_problems, int k_per,
-                                                      unsigned long long seed, int32_t* __restrict__ idx) {
+                                                      unsigned long long seed, unsigned problem_base,
+                                                      int32_t* __restrict__ idx) {
     const int t = blockIdx.x * 256 + threadIdx.x;
     if (t >= n_problems * k_per) return;
     const int p = t / k_per, hyp = t - p * k_per;
     const int m = offsets[p + 1] - offsets[p];
-    uint32_t c[4] = {(uint32_t)hyp, (uint32_t)p, 0u, 0u};
+    uint32_t c[4] = {(uint32_t)hyp, problem_base + (uint32_t)p, 0u, 0u};
     philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     int id[4] = {0, 0, 0, 0};
     if (m >= 4) {
@@ -512,12 +513,13 @@ extern "C" int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int
 }
 
 extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, const int32_t* d_offsets, int n_problems,
-                                  int m_max, int k, int32_t* d_idx, uint64_t seed, double th, int loss,
-                                  const int32_t* d_need, float* d_h, uint8_t* d_flags, int32_t* d_counts,
+                                  int m_max, int k, int32_t* d_idx, uint64_t seed, int64_t problem_base, double th,
+                                  int loss, const int32_t* d_need, float* d_h, uint8_t* d_flags, int32_t* d_counts,
                                   uint64_t* d_masks, uint64_t* d_best, unsigned flags, void* stream) {
     using namespace rwh;
     if (!d_pts_a || !d_pts_b || !d_offsets || !d_idx || !d_need || !d_h || !d_flags || !d_counts || !d_best) return RWH_E_INVALID;
     if (n_problems < 0 || k < 0 || m_max <= 0) return RWH_E_INVALID;
+    if (problem_base < 0 || problem_base + n_problems > 0xFFFFFFFFll) return RWH_E_INVALID;
     if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ) return RWH_E_INVALID;
     if (n_problems == 0 || k == 0) return RWH_OK;
     const long long total = (long long)n_problems * k;
@@ -525,7 +527,7 @@ extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, co
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (flags & RWH_BATCH_DEVICE_SAMPLING)
         hipLaunchKernelGGL(sample4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_offsets, n_problems, k,
-                           (unsigned long long)seed, d_idx);
+                           (unsigned long long)seed, (unsigned)problem_base, d_idx);
     launch_dlt4(s, d_pts_a, d_pts_b, m_max, d_idx, (int)total, d_h, d_flags, d_offsets, k,
                 reinterpret_cast<unsigned long long*>(d_best), 2 * n_problems);   // also clears the P x 2 keys
     int hpw = (int)(total / (256 * 4 * 32));

@@ -151,12 +151,13 @@ class BatchWorkspace:
         self.best = torch.zeros((n_problems, 2), dtype=torch.int64, device=device)
 
 
-def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=None):
+def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=None, problem_base=0):
     """P independent RANSAC searches in one library call (rwh_ransac_batched, include/rwh.h).
 
     pts_a/pts_b: [total,2] float32 (the problems' correspondences concatenated), offsets: [P+1] int32,
     needs: [P] int32 -- all on the GPU.  Either `idx` ([P,K,4] int32, problem-local indices, the caller's
-    sampler: parity with `ransac_search`) or `seed` (device Philox sampling, non-parity) must be given.
+    sampler: parity with `ransac_search`) or `seed` (device Philox sampling, non-parity; `problem_base` = global
+    index of the first problem when a longer list is sharded over calls) must be given.
     Results land in `ws` (ws.idx holds the samples actually used)."""
     lib = _lib.load()
     _dev_check(pts_a, pts_b, offsets, needs)
@@ -170,7 +171,7 @@ def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=No
         assert tuple(idx.shape) == (P, ws.k, 4) and idx.dtype == torch.int32
         ws.idx.copy_(idx)
     check(lib.rwh_ransac_batched(_ptr(pts_a), _ptr(pts_b), _ptr(offsets), P, ws.m_max, ws.k, _ptr(ws.idx),
-                                 int(seed or 0) & 0xFFFFFFFFFFFFFFFF, float(th), RWH_LOSS[loss], _ptr(needs), _ptr(ws.H),
+                                 int(seed or 0) & 0xFFFFFFFFFFFFFFFF, int(problem_base), float(th), RWH_LOSS[loss], _ptr(needs), _ptr(ws.H),
                                  _ptr(ws.flags), _ptr(ws.counts), _ptr(ws.masks) if ws.masks is not None else None,
                                  _ptr(ws.best), flags, _lib.stream_ptr()), "rwh_ransac_batched")
     return ws

@@ -196,7 +196,7 @@ class RANSAC(object):
         return finalModel, inliers, totalfit
 
 
-def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None):
+def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None, problem_base=0):
     """RANSAC over MANY image pairs in one GPU submission (the reference has no
     counterpart: its RANSAC.run handles one pair per call, ransac.py:159-213).
 
@@ -209,7 +209,9 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None)
     a documented NON-PARITY mode -- the reference draws with replacement from numpy's global legacy generator
     (ransac.py:177).  Pass `idx` (list of [k,4] integer arrays, one per problem) to supply the samples yourself; each
     problem's result then equals `RANSAC.run` on that table bit for bit.  The early-exit rule (ransac.py:186-190)
-    holds per problem either way: the first hypothesis whose count reaches M*d/100 + n wins."""
+    holds per problem either way: the first hypothesis whose count reaches M*d/100 + n wins.  `problem_base`: global
+    index of datas[0] when a longer problem list is split over several calls (sharded.run_batch_sharded), so that the
+    device sampler draws the tables of the unsplit run."""
     import torch
     if method not in _lib.RWH_LOSS:
         exit("Invalid method!")
@@ -233,7 +235,8 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None)
         table = torch.from_numpy(np.stack([np.asarray(t).astype(np.int32) for t in idx])).to(dev)
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, idx=table)
     else:
-        kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed)
+        kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed,
+                               problem_base=problem_base)
     best = ws.best.cpu().numpy()
     winners = [kernels.decode_best(best[p], int(k)) for p in range(P)]
     rows = torch.tensor([[p, w[0] if w[0] is not None else 0] for p, w in enumerate(winners)], device=dev)

@@ -7,6 +7,8 @@ xGMI on ROCm; "gloo" in the CPU tests).
     first-index tie-break and early-exit semantics (ransac.py:186-202).  16 bytes: pure latency.
   * The warp shards by output-row tiles (one image) or by image (a batch); rows and images are
     independent, so there is NO collective on that path and outputs stay sharded.
+  * Batched RANSAC (many image pairs) shards by problem: each rank runs `run_batch` on its contiguous slice of the
+    problem list, no collective; results stay sharded unless the caller asks for an all-gather of the (small) results.
 
 The scoring backend is injectable so that the sharding / reduction logic is testable on CPU
 ranks (the CPU tests plug the oracle in; the product default is the HIP kernels).
@@ -77,3 +79,23 @@ def warp_row_shard(src, inv_h, grid, bound_hw, interp, out_dtype, group=None):
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     rows = shard_range(grid.out_h, rank, world)
     return kernels.warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, rows=rows), rows
+
+
+def run_batch_sharded(datas, gather=False, solve=None, group=None, **kw):
+    """Many-pair RANSAC over the ranks: rank r solves problems shard_range(len(datas), r, world) with
+    `ransac.run_batch(slice, **kw)` (or the injected `solve`), in one GPU submission per rank.  Device sampling stays
+    a function of (seed, GLOBAL problem index, hypothesis): pass `seed`, and every problem gets the table it would get
+    in a single-rank run.  Returns (results of this rank's slice, (begin, end)); with gather=True every rank receives
+    the full list instead (one all_gather of small Python objects: a 3x3 matrix and an index array per problem)."""
+    dist = _dist()
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    b, e = shard_range(len(datas), rank, world)
+    if solve is None:
+        from .ransac import run_batch as solve
+    mine = solve(datas[b:e], problem_base=b, **kw) if e > b else []
+    if not gather or world == 1:
+        return mine, (b, e)
+    parts = [None] * world
+    dist.all_gather_object(parts, mine, group=group)
+    return [r for part in parts for r in part], (0, len(datas))

@@ -361,9 +361,18 @@ def test_batched_device_sampling(gpu, matches):
     kernels.ransac_batched(pa[:sizes[0] + sizes[1]], pb[:sizes[0] + sizes[1]], offsets[:3].contiguous(), needs[:2].contiguous(),
                            5.0, "fwd", ws2, seed=seed)
     assert torch.equal(ws2.best, ws.best[:2]) and torch.equal(ws2.counts, ws.counts[:2])
+    # a problem list split over two calls draws the tables of the unsplit call (problem_base = global index)
+    o2 = (offsets[2:] - offsets[2]).contiguous()
+    ws3 = kernels.BatchWorkspace(3, K, max(sizes[2:]), gpu)
+    kernels.ransac_batched(pa[int(offsets[2]):].contiguous(), pb[int(offsets[2]):].contiguous(), o2, needs[2:].contiguous(),
+                           5.0, "fwd", ws3, seed=seed, problem_base=2)
+    assert torch.equal(ws3.idx, ws.idx[2:]) and torch.equal(ws3.best, ws.best[2:]) and torch.equal(ws3.counts, ws.counts[2:])
     # host wrapper: finds the panorama homography's inlier set size class on the full problem, early exit at d=40
     res = rmod.run_batch(probs[:3], th=5, d=70, k=2000, method="fwd", seed=7)
     assert 110 <= int(res[0][2]) <= 125 and res[0][0].shape == (3, 3) and res[0][0].dtype == np.float64
+    tail = rmod.run_batch(probs[1:3], th=5, d=70, k=2000, method="fwd", seed=7, problem_base=1)
+    for a, b in zip(res[1:3], tail):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1][0], b[1][0]) and int(a[2]) == int(b[2])
     res40 = rmod.run_batch(probs[:3], th=5, d=40, k=2000, method="fwd", seed=7)
     for (X, _), r in zip(probs[:3], res40):
         assert int(r[2]) >= X.shape[1] * 40 / 100 + 4

@@ -87,3 +87,39 @@ def test_ransac_sharded_world2_matches_sequential(tmp_path, need):
         assert winner == 6354 - 6300 and not early    # the golden winner, no early exit (best 121 < 134)
     else:
         assert early                                   # some hypothesis reaches 110 first
+
+
+def _batch_rank_main(rank, world, port, result_path):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    calls = []
+
+    def solve(slice_, problem_base=0, **kw):      # stands in for ransac.run_batch (GPU): echoes what it was asked to do
+        calls.append((len(slice_), problem_base, kw.get("seed")))
+        return [(np.full((3, 3), float(problem_base + i)), (np.arange(d[0].shape[1]),), d[0].shape[1])
+                for i, d in enumerate(slice_)]
+
+    datas = [[np.zeros((2, 10 + p)), np.zeros((2, 10 + p))] for p in range(5)]
+    mine, span = sharded.run_batch_sharded(datas, solve=solve, seed=9)
+    full, fspan = sharded.run_batch_sharded(datas, gather=True, solve=solve, seed=9)
+    ok = (span == sharded.shard_range(5, rank, world) and len(mine) == span[1] - span[0]
+          and all(int(r[0][0, 0]) == span[0] + i for i, r in enumerate(mine))
+          and fspan == (0, 5) and [int(r[0][0, 0]) for r in full] == [0, 1, 2, 3, 4]
+          and [int(r[2]) for r in full] == [10, 11, 12, 13, 14]
+          and calls == [(span[1] - span[0], span[0], 9)] * 2)
+    t = torch.tensor([int(ok)])
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        np.save(result_path, t.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_run_batch_sharded_world2(tmp_path):
+    """Problem list split over 2 gloo ranks: contiguous slices, the global problem index handed to the solver (device
+    sampling stays a function of it), results sharded by default and identical everywhere after the optional gather."""
+    port = 29500 + (os.getpid() % 400) + 517
+    out = str(tmp_path / "res.npy")
+    mp.spawn(_batch_rank_main, args=(2, port, out), nprocs=2, join=True)
+    assert int(np.load(out)[0]) == 1
