@@ -1,32 +1,34 @@
 // K3 fast path: RGB u8 source, bilinear, u8 (truncated) or f32 output -- the BASELINE configuration.
 //
-// What bounds this kernel on MI355X (measured, see DESIGN.md section 5): not HBM.  A direct gather
+// What bounds this kernel on MI355X (measured, see DESIGN.md section 4): not HBM.  A direct gather
 // version (one lane = 4 output pixels, two unaligned 8-byte loads per pixel) is bound first by the
 // texture-address unit (a 64-lane gather costs ~16 cycles per dword per lane-quad, i.e. one TA cycle
 // per pixel per CU) and, once that is fixed, by VALU issue: every VALU instruction, float32 or
 // float64, costs ~4.2 cycles per wave on gfx950 and only v_pk_*_f32 does two lanes' worth per issue.
-// So the design goal is "few instructions per pixel", and loads that are wide and coalesced:
+// The final 8-pixel-per-lane kernel issues 440 VALU instructions per wave (55 per pixel) and keeps the
+// VALU ~85-90 % busy.  So the design goal is "few instructions per pixel", and loads that are wide and coalesced:
 //
-//   * one wave = a 64 x 4 output patch, one lane = 4 consecutive pixels of one patch row;
 //   * X, Y, W of a pixel are affine in (row, column): lane setup is two float64 FMAs per coordinate
-//     from host-precomputed coefficients, the lane's other three pixels are one add each;
-//   * ONE v_rcp_f64 per lane: its four W are inverted together (Montgomery batch inversion);
+//     from host-precomputed coefficients, every further pixel is one add each;
+//   * few reciprocals: a run of pixels shares ONE v_rcp_f64 (Montgomery batch inversion);
 //   * floor / fraction / weights come from the float64 "magic number" u = s + 1.5*2^20 (ulp 2^-32):
-//     hi(u) - 0x41380000 = floor(s), lo(u) = frac(s) * 2^32; w = cvt(lo) and 1-w = cvt(~lo) are both
+//     hi(u) - 0x41380000 = floor(s), lo(u) = frac(s) * 2^32; w = cvt(lo) and 2^32 - w are both
 //     correct to float32 rounding; the 2^-64 scale of (x weight)*(y weight) rides on the y weights;
 //   * the patch's source footprint is the bounding box of its four mapped corners (extremes of a
 //     projective map over a rectangle sit at the corners while W keeps its sign); if it lies strictly
 //     inside the image the wave needs NO per-pixel bounds logic, and it copies the footprint into a
-//     wave-private LDS slab with coalesced 12-byte loads (21 lanes per source row, 3 rows per
-//     instruction), expanding RGB to 4-byte RGBX texels so that the bilinear taps are 4-byte aligned
-//     ds_read2_b32 pairs (8-byte LDS reads at 4-byte alignment stall as "unaligned");
+//     wave-private LDS slab with coalesced 12-byte loads, expanding RGB to 4-byte RGBX texels so that the
+//     bilinear taps are 4-byte aligned ds_read2_b32 pairs (8-byte LDS reads at 4-byte alignment stall as
+//     "unaligned");
 //   * waves that touch the border, cross the horizon, or have a footprint that does not fit the slab
-//     (strong zoom-out / rotation) take a masked gather path straight from global memory, with a
-//     byte-exact guard for the last source rows so nothing is read past the image;
+//     (strong zoom-out) take a masked gather path straight from global memory, with a byte-exact guard for
+//     the last source rows so nothing is read past the image;
 //   * the blend is the 4-weight form on packed float32 pairs (pixel j | pixel j+1);
 //   * u8 output: v_cvt_pk_u8_f32 converts + packs a byte per instruction; it rounds to nearest, so the
 //     accumulator starts at -0.5 + 2^-15: exact integers (weights 0/1) land on themselves, anything else
 //     is floor(v + 3e-5), inside the float32 blend's own noise.
+// Two kernels: warp_rgb8_fast (4 px per lane, 64 x 4 patches, fixed 9 x 84-texel slab; outputs narrower than
+// 128 px) and warp_rgb8_fast8 (8 px per lane, three patch shapes, slab capacity as an area; everything else).
 // No MFMA: there is no dense contraction on this path.
 #pragma once
 #include "rwh_common.h"
