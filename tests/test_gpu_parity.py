@@ -561,6 +561,44 @@ def test_warp_patch_shapes_vs_oracle(gpu, case, shape, monkeypatch):
     assert np.array_equal(part, u8[100:229])
 
 
+@pytest.mark.parametrize("block", range(4))
+def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
+    """Random homographies (rotation, anisotropic scale 0.6-1.8, shear, perspective, translation), random source and
+    output sizes (narrower and wider than one 128-pixel tile), random patch shape: fast kernels vs the oracle."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(1000 + block)
+    for case in range(10):
+        sh, sw = int(rng.integers(24, 260)), int(rng.integers(24, 420))
+        img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        t = rng.uniform(-np.pi, np.pi) if case % 2 else rng.uniform(-0.1, 0.1)
+        sx, sy = rng.uniform(0.6, 1.8, 2)
+        A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.array([[sx, rng.uniform(-0.2, 0.2)], [0, sy]])
+        H = np.eye(3)
+        H[:2, :2] = A
+        H[:2, 2] = rng.uniform(-40, 40, 2) + np.array([sw / 2, sh / 2]) - A @ np.array([sw / 2, sh / 2])
+        H[2, :2] = rng.uniform(-4e-4, 4e-4, 2)
+        inv = np.linalg.inv(H)
+        ow, oh = int(rng.integers(8, 520)), int(rng.integers(5, 300))
+        x0, y0 = rng.uniform(-30, 30, 2)
+        stepx, stepy = rng.uniform(0.7, 1.3, 2)
+        xs, ys = x0 + stepx * np.arange(ow), y0 + stepy * np.arange(oh)
+        grid = kernels.Grid(xs[0], xs[-1], ow, ys[0], ys[-1], oh)
+        xs, ys = np.linspace(xs[0], xs[-1], ow), np.linspace(ys[0], ys[-1], oh)
+        shape = [None, "5", "6", "7"][int(rng.integers(0, 4))]
+        if shape is None:
+            monkeypatch.delenv("RWH_WARP_SHAPE", raising=False)
+        else:
+            monkeypatch.setenv("RWH_WARP_SHAPE", shape)
+        ref = _oracle_warp_on_grid(img, inv, xs, ys, (sh, sw))
+        src = torch.from_numpy(img).to(gpu)
+        got = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.float32).cpu().numpy()
+        ok = close(got, ref)
+        assert (~ok).sum() <= 3, (block, case, shape, (sh, sw), (oh, ow), int((~ok).sum()), float(np.abs(got - ref).max()))
+        u8 = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8).cpu().numpy()
+        d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
+        assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (block, case, shape, int((d > 1).sum()), float((d != 0).mean()))
+
+
 # ------------------------------------------------------------------------------------------------
 # Exact mode (RWH_WARP_EXACT): bit-identical float64 / uint8 results
 # ------------------------------------------------------------------------------------------------
