@@ -409,6 +409,50 @@ def test_scorer_threshold_edges(gpu):
                 assert np.array_equal(bits, want) and int(counts[i]) == int(want.sum()), (method, th, i)
 
 
+@pytest.mark.parametrize("M", [64, 65, 256, 257, 1000])
+def test_scorer_any_number_of_correspondences(gpu, M):
+    """SURVEY 8d scaling set: synthetic correspondences (Hs-projected uniform points + 1 px noise + 40 % outliers).
+    M <= 256 keeps the points in registers (1..4 mask words), larger M streams them: K1 + K2 + accept rules against
+    the oracle hypothesis by hypothesis, all three losses, single search and the batched entry point."""
+    from oracle import rwh_oracle as orc
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(42 + M)
+    Hs = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+    A = rng.uniform(0, 4000, (M, 2))
+    P = np.c_[A, np.ones(M)] @ Hs.T
+    B = P[:, :2] / P[:, 2:] + rng.normal(0, 1.0, (M, 2))
+    out = rng.random(M) < 0.4
+    B[out] = rng.uniform(0, 4000, (int(out.sum()), 2))
+    A, B = A.astype(np.float32), B.astype(np.float32)
+    X, Y = A.T.copy(), B.T.copy()
+    K = 200
+    idx = rng.integers(0, M, (K, 4))
+    pa, pb = torch.from_numpy(A).to(gpu), torch.from_numpy(B).to(gpu)
+    idx_d = torch.from_numpy(idx.astype(np.int32)).to(gpu)
+    need = kernels.need_count(M, 50, 4)
+    for method in ("fwd", "backward", "reproj"):
+        Href, cref = orc.ransac_table(X, Y, idx, th=3, method=method)
+        ws = kernels.SearchWorkspace(K, M, gpu)
+        kernels.ransac_search(pa, pb, idx_d, 3.0, method, need, ws)
+        same = np.all(ws.H.cpu().numpy().view(np.uint32) == Href.view(np.uint32), axis=1)
+        c = ws.counts.cpu().numpy()
+        nd = np.array([len(set(r)) == 4 for r in idx.tolist()])   # repeated samples are singular: NaN here, arbitrary in LAPACK
+        assert np.array_equal((ws.flags.cpu().numpy() & 1).astype(bool), ~nd)
+        assert same[nd].mean() > 0.95 and np.array_equal(c[same], cref[same]), (M, method, float(same[nd].mean()))
+        assert np.abs(c - cref)[nd].max() <= 3                 # a 1-ulp H moves at most a few borderline pairs
+        # masks agree with the counts; bits past M are clear
+        bits = np.unpackbits(ws.masks.cpu().numpy().view(np.uint8), axis=1, bitorder="little")
+        assert np.array_equal(bits.sum(axis=1), c) and not bits[:, M:].any()
+        # accept rules on the GPU's own counts
+        w, _, early = kernels.decode_best(ws.best.cpu().numpy(), K)
+        assert (w, early) == orc.select_winner(c, need)
+        # the batched entry point with this single problem gives the same bits
+        bws = kernels.BatchWorkspace(1, K, M, gpu)
+        kernels.ransac_batched(pa, pb, torch.tensor([0, M], dtype=torch.int32, device=gpu),
+                               torch.tensor([need], dtype=torch.int32, device=gpu), 3.0, method, bws, idx=idx_d.view(1, K, 4))
+        assert torch.equal(bws.counts[0], ws.counts) and torch.equal(bws.masks[0], ws.masks) and torch.equal(bws.best[0], ws.best)
+
+
 def test_model_helpers_match_oracle(gpu, matches):
     import ransac as rs
     from oracle import rwh_oracle as orc
