@@ -378,8 +378,11 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
     a.row_begin = w.row_begin; a.rows = w.rows;
     const int shape = px8 ? choose_shape(a) : 0;
-    for (int j = 1; j <= 7; ++j) {   // column offsets of a lane's pixels: 1..3 (4 px kernel); 1..3, PW/2 .. PW/2+3 (8 px kernel)
-        const double o4 = (double)j, o8 = (double)(j < 4 ? j : (px8 ? (1 << shape) / 2 : 4) + j - 4);
+    // column offsets of a lane's pixels: 1..3 (4 px kernel); 8 px kernel: two runs PW/2 apart, pixels of a run 1 column
+    // apart (uint8 output) or PW/8 columns apart (float32 output, rwh_warp_rgb8.h)
+    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << shape) / 8 : 1;
+    for (int j = 1; j <= 7; ++j) {
+        const double o4 = (double)j, o8 = (double)(j < 4 ? j * pstr : (px8 ? (1 << shape) / 2 : 4) + (j - 4) * pstr);
         for (int q = 0; q < 3; ++q) {
             const double c = q == 0 ? a.cx[2] : q == 1 ? a.cy[2] : a.cw[2];
             a.dxs8[j - 1][q] = o8 * c;

@@ -107,7 +107,10 @@ __device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, floa
 
 // Blend 4 pixels (taps a0 = texel(iy,ix), b0 = texel(iy,ix+1), a1/b1 = row iy+1; R,G,B in bytes 0..2)
 // and store them.  `full`: the lane owns all 4 pixels; otherwise it owns local pixels j >= shift.
-template <typename DstT>
+// PSTR > 1 (float32 output of the 8 px kernel): the four pixels are PSTR columns apart, pixel j is stored (12 bytes)
+// at drow + 3*j*PSTR if j*PSTR >= shift -- neighbouring lanes then write neighbouring pixels in every store
+// instruction (four consecutive float32 pixels per lane = 48-byte lane stride cost 2.7x the time).
+template <typename DstT, int PSTR = 1>
 __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                             const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                             const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
@@ -136,6 +139,16 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
 #ifdef RWH_ABL_NOSTORE  // tools/warp_lab ablation hook (never defined in the product build)
     if (o[0][0] + o[1][1] + o[2][2] + o[3][0] != -12345.f) return;
 #endif
+    if constexpr (PSTR > 1) {
+        static_assert(!U8, "strided runs are the float32 layout");
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j)
+            if (j * PSTR >= shift) {
+                const pk3 w = {__float_as_uint(o[j][0]), __float_as_uint(o[j][1]), __float_as_uint(o[j][2])};
+                __builtin_memcpy(drow + 3 * j * PSTR, &w, 12);
+            }
+        return;
+    }
     if (shift == 0) {
         if constexpr (U8) {
             pk3 w;
@@ -427,11 +440,13 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     const int rr = min(rr_raw, a.rows - 1);                   // rows past the shard recompute its last row
     // a lane owns two runs of 4 pixels, PW/2 pixels apart: every store instruction then writes LPR lanes x 12 B of
     // contiguous bytes per patch row (8 contiguous pixels per lane would leave 12-byte holes in every store).
+    // uint8 output: a run = 4 consecutive pixels (12 bytes); float32 output: 4 pixels LPR columns apart (12 bytes each).
     // A tile that sticks out of the row is moved left as a whole and owns only the columns >= its nominal start.
     const int tcol0 = (int)tx * 128;
     const int tcol = min(tcol0, a.out_w - 128);
     const int tshift = tcol0 - tcol;                          // uniform
-    const int lcol = wave_x + pq * 4;                         // column inside the tile
+    constexpr int PSTR = sizeof(DstT) == 1 ? 1 : LPR;         // column stride inside a run (float32 output: interleaved)
+    const int lcol = wave_x + pq * (PSTR == 1 ? 4 : 1);       // column inside the tile
     const int c0p = tcol + lcol;
     const bool store_any = rr_raw < a.rows;
 
@@ -575,8 +590,9 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
                 a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
 #endif
             }
-            const int first = tshift - (lcol + (PW / 2) * h);   // local pixels j >= first are this tile's
-            blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h, store_any & (first < 4), max(first, 0));
+            const int first = tshift - (lcol + (PW / 2) * h);   // local pixels at columns >= first are this tile's
+            blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                                    store_any & (first <= 3 * PSTR), max(first, 0));
         }
         return;
     }
@@ -619,7 +635,8 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
             }
         }
         const int first = tshift - (lcol + (PW / 2) * h);
-        blend_store<DstT>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h, store_any & (first < 4), max(first, 0));
+        blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                                store_any & (first <= 3 * PSTR), max(first, 0));
     }
 }
 
