@@ -86,6 +86,11 @@ __device__ __forceinline__ uint32_t mad24_s(uint32_t a, uint32_t b_uniform, uint
     asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b_uniform), "v"(c));
     return r;
 }
+__device__ __forceinline__ uint32_t shl2_add_s(uint32_t a, uint32_t c_uniform) {    // (a << 2) + c, one instruction
+    uint32_t r;                                                                      // (LLVM spells hi32(double) << 2 as
+    asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(a), "s"(c_uniform));          //  alignbit + and + add otherwise)
+    return r;
+}
 __device__ __forceinline__ uint32_t mul24_12(uint32_t a) {                          // inline constant
     uint32_t r;
     asm("v_mul_u32_u24 %0, %1, 12" : "=v"(r) : "v"(a));
@@ -581,7 +586,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 weights(lx[j], ly[j], W_SCALE, W_ONE, wx0[j], wx1[j], wy0[j], wy1[j]);
-                const uint32_t lo = mad24_s(hy[j], lpitch, (hx[j] << 2) - tap_c);
+                const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
 #else
