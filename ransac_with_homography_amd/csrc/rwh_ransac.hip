@@ -38,11 +38,14 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
                                                   float* __restrict__ hout, uint8_t* __restrict__ flags,
                                                   const int32_t* __restrict__ offsets, int k_per,
                                                   unsigned long long* __restrict__ reset_keys, int n_reset) {
+    __shared__ float hstage[64 * 9];
     const int t = blockIdx.x * 64 + threadIdx.x;
     // a search's packed argmax keys are cleared here instead of by a memset launch of their own (the grid always
     // covers n_reset threads, see launch_dlt4)
     if (reset_keys && t < n_reset) reset_keys[t] = 0ull;
-    if (t >= k) return;
+    if (blockIdx.x * 64 >= k) return;             // whole wave past the end
+    const bool live = t < k;
+    if (!live) idx = nullptr;                     // lanes past the end compute on point 0 and store nothing
     if (offsets) {
         const int p = t / k_per;
         const int base = offsets[p];
@@ -51,11 +54,11 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     }
     int id[4];
     bool bad_index = false;
+    const int4 raw = idx ? reinterpret_cast<const int4*>(idx)[t] : int4{0, 0, 0, 0};   // one 16-byte load per lane
+    id[0] = raw.x; id[1] = raw.y; id[2] = raw.z; id[3] = raw.w;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        id[i] = idx[4 * t + i];
+    for (int i = 0; i < 4; ++i)
         if (id[i] < 0 || id[i] >= m) { bad_index = true; id[i] = 0; }
-    }
     const bool repeated = (id[0] == id[1]) | (id[0] == id[2]) | (id[0] == id[3]) | (id[1] == id[2]) |
                           (id[1] == id[3]) | (id[2] == id[3]);
 
@@ -64,8 +67,8 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     double M[4][9];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float x = pa[2 * id[i]], y = pa[2 * id[i] + 1];
-        const float xp = pb[2 * id[i]], yp = pb[2 * id[i] + 1];
+        const float2 A = reinterpret_cast<const float2*>(pa)[id[i]], Bp = reinterpret_cast<const float2*>(pb)[id[i]];
+        const float x = A.x, y = A.y, xp = Bp.x, yp = Bp.y;
         M[i][0] = -(double)x;  M[i][1] = -(double)y;  M[i][2] = -1.0;
         M[i][3] = (double)(x * xp);  M[i][4] = (double)(y * xp);  M[i][5] = -(double)xp;  // float32 products
         M[i][6] = (double)(x * yp);  M[i][7] = (double)(y * yp);  M[i][8] = -(double)yp;
@@ -131,9 +134,20 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     for (int i = 0; i < 9; ++i) {
         const float v = n[i] / n[8];
         finite &= (fabsf(v) <= 3.4028234664e38f);  // false for NaN / inf
-        hout[9 * t + i] = v;
+        hstage[9 * threadIdx.x + i] = v;
     }
-    flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR));
+    if (live) flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR));
+    // the wave's 64 x 9 floats leave as 9 coalesced 256-byte stores (lane-strided 36-byte records would be 9 scattered ones)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const int nfl = 9 * min(64, k - (int)blockIdx.x * 64);
+    float* wout = hout + 9 * (size_t)blockIdx.x * 64;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const int f = i * 64 + threadIdx.x;
+        if (f < nfl) wout[f] = hstage[f];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
