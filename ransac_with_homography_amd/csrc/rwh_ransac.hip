@@ -33,6 +33,16 @@ __device__ __forceinline__ void swap_if(bool c, double& a, double& b) {
 
 // Batched mode (rwh_ransac_batched): `offsets` != NULL; hypothesis t belongs to problem t / k_per, whose correspondences
 // are rows offsets[p] .. offsets[p+1]-1 of pa / pb, and idx holds indices local to the problem.
+// 1/v to float64 round-off (v_rcp_f64 + two Newton steps: ~1.1e-16 relative), ~10 instructions where an IEEE divide
+// takes ~35.  K1's float64 solve is an elimination of our own choosing, not LAPACK's sequence: any float64-accurate
+// result rounds to the same float32 H (except on float32 rounding boundaries, where LAPACK's own round-off decides too).
+__device__ __forceinline__ double recip(double v) {
+    double r = __builtin_amdgcn_rcp(v);
+    r = fma(fma(-v, r, 1.0), r, r);
+    r = fma(fma(-v, r, 1.0), r, r);
+    return r;
+}
+
 __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, const float* __restrict__ pb, int m,
                                                   const int32_t* __restrict__ idx, int k,
                                                   float* __restrict__ hout, uint8_t* __restrict__ flags,
@@ -90,10 +100,10 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
 #pragma unroll
             for (int j = c; j < 9; ++j) swap_if(sw, M[c][j], M[i][j]);
         }
-        const double piv = M[c][c];
+        const double rpiv = recip(M[c][c]);
 #pragma unroll
         for (int i = c + 1; i < 4; ++i) {
-            const double f = M[i][c] / piv;
+            const double f = M[i][c] * rpiv;
 #pragma unroll
             for (int j = c + 1; j < 9; ++j) M[i][j] = M[i][j] - f * M[c][j];
         }
@@ -103,21 +113,23 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     double a21 = M[3][6], a22 = M[3][7], b2 = M[3][8];
     const bool sw2 = fabs(a21) > fabs(a11);
     swap_if(sw2, a11, a21); swap_if(sw2, a12, a22); swap_if(sw2, b1, b2);
-    const double f2 = a21 / a11;
+    const double ra11 = recip(a11);
+    const double f2 = a21 * ra11;
     const double d2 = a22 - f2 * a12;
-    const double h8 = (b2 - f2 * b1) / d2;
-    const double h7 = (b1 - a12 * h8) / a11;
+    const double h8 = (b2 - f2 * b1) * recip(d2);
+    const double h7 = (b1 - a12 * h8) * ra11;
 
     double h[9];
+    const double rm22 = recip(M[2][2]), rm11 = recip(M[1][1]), rm00 = recip(M[0][0]);
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) {  // blk 0: h1..h3 from cols 3..5, blk 1: h4..h6 from cols 6..8
         const int q = 3 + 3 * blk;
         const double t2 = M[2][q + 2] - M[2][q] * h7 - M[2][q + 1] * h8;
-        const double r2 = t2 / M[2][2];
+        const double r2 = t2 * rm22;
         const double t1 = M[1][q + 2] - M[1][q] * h7 - M[1][q + 1] * h8 - M[1][2] * r2;
-        const double r1 = t1 / M[1][1];
+        const double r1 = t1 * rm11;
         const double t0 = M[0][q + 2] - M[0][q] * h7 - M[0][q + 1] * h8 - M[0][1] * r1 - M[0][2] * r2;
-        const double r0 = t0 / M[0][0];
+        const double r0 = t0 * rm00;
         h[3 * blk] = r0; h[3 * blk + 1] = r1; h[3 * blk + 2] = r2;
     }
     h[6] = h7; h[7] = h8; h[8] = 1.0;
@@ -125,10 +137,10 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     double ss = 0.0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) ss = ss + h[i] * h[i];
-    const double nrm = sqrt(ss);
+    const double rnrm = recip(sqrt(ss));
     float n[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) n[i] = (float)(h[i] / nrm);
+    for (int i = 0; i < 9; ++i) n[i] = (float)(h[i] * rnrm);
     bool finite = true;
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
