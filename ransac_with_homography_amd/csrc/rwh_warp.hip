@@ -366,7 +366,7 @@ static int choose_shape(const FastArgs& a) {
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
                 int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
                 void (*custom)(const FastArgs) = nullptr) {
-    const bool px8 = variant >= 1;
+    const bool px8 = variant >= 1, nn = variant == 3;       // 3: nearest neighbour on the 8 px kernel's tiling
     if (w.out_w < (px8 ? 128 : FP_PX) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
     const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
     if ((size_t)w.rows * (size_t)w.out_w * 3 * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
@@ -377,6 +377,9 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.cw[0] = ih[6] * x0 + ih[7] * y0 + ih[8]; a.cw[1] = ih[7] * step_y; a.cw[2] = ih[6] * step_x;
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
     a.row_begin = w.row_begin; a.rows = w.rows;
+    for (int i = 0; i < 9; ++i) a.ih[i] = ih[i];
+    a.gx0 = w.x0; a.gstep_x = w.step_x; a.gx_last = w.x_last; a.gy0 = w.y0; a.gstep_y = w.step_y; a.gy_last = w.y_last;
+    a.out_h = w.out_h;
     const int shape = px8 ? choose_shape(a) : 0;
     // column offsets of a lane's pixels: 1..3 (4 px kernel); 8 px kernel: two runs PW/2 apart, pixels of a run 1 column
     // apart (uint8 output) or PW/8 columns apart (float32 output, rwh_warp_rgb8.h)
@@ -406,7 +409,8 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     void (*kern)(const FastArgs) = custom;
     if (!kern) {
         const bool u8 = dst_dtype == RWH_U8;
-        if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
+        if (nn) kern = shape == 7 ? warp_rgb8_nn<7> : shape == 6 ? warp_rgb8_nn<6> : warp_rgb8_nn<5>;
+        else if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
         else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
         else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
         else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
@@ -465,6 +469,12 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     a.nblocks = (unsigned)nb;
     a.cpx = (a.nblocks + 7u) / 8u;
 
+    // nearest neighbour, RGB u8: one kernel for the exact and the default mode -- it is bit-exact by construction
+    if (src_dtype == RWH_U8 && channels == 3 && interp == RWH_NEAREST && dst_dtype == RWH_U8 && a.out_w >= 128 &&
+        (size_t)src_h * src_w * 3 < (1ull << 32) - 4) {
+        const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*variant=*/3);
+        if (st != RWH_E_UNSUPPORTED) return st;
+    }
     if (flags & RWH_WARP_EXACT) {
         if (src_dtype == RWH_U8) return channels == 3 ? dispatch_exact<unsigned char, 3>(a, interp, dst_dtype, s)
                                                       : dispatch_exact<unsigned char, 4>(a, interp, dst_dtype, s);

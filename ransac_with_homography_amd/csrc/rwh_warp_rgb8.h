@@ -63,6 +63,10 @@ struct FastArgs {
     unsigned tiles_x, tiles_y, nblocks, cpx;
     unsigned tiles_x_magic, tiles_y_magic;               // floor(n/d) = umulhi(n, magic) for n < nblocks
     int group;                                           // free parameter of a tools/warp_lab custom kernel
+    // nearest-neighbour kernel only: the reference's own formula for the (rare) pixels it re-derives exactly
+    double ih[9];                                        // inv(H), row major
+    double gx0, gstep_x, gx_last, gy0, gstep_y, gy_last; // numpy.linspace output grid
+    int out_h;
 };
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_as_longlong(v) >> 32); }
@@ -642,6 +646,193 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
         const int first = tshift - (lcol + (PW / 2) * h);
         blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
                                 store_any & (first <= 3 * PSTR), max(first, 0));
+    }
+}
+
+// ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
+// Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
+// The pixel index trunc(s + 0.5) is an INTEGER result, so "within 2^-32 px" is not good enough near a tie:
+//   * interior waves take floor(s + 0.5) from the magic number (coordinates good to ~3e-10 px) and flag every pixel whose
+//     fraction lies within 2^-20 px of a rounding boundary (2e-6 of all pixels); flagged pixels are recomputed with the
+//     reference's own formula -- numpy.linspace grid, dgemm-order products, IEEE float64 divide, (int)(s + 0.5), the
+//     one warp_exact uses -- and fetched from global memory;
+//   * border / horizon / oversize waves use that formula for every pixel (negative coordinates truncate towards zero
+//     there, which floor() does not reproduce).
+constexpr uint32_t NN_TIE = 1u << 12;                   // 2^-20 px in units of 2^-32
+
+__device__ __forceinline__ uint32_t nn_exact_texel(const FastArgs& a, const unsigned char* simg, int r, int c) {
+    const double x = (c == a.out_w - 1) ? a.gx_last : (double)c * a.gstep_x + a.gx0;
+    const double y = (r == a.out_h - 1) ? a.gy_last : (double)r * a.gstep_y + a.gy0;
+    const double X = fma(a.ih[1], y, a.ih[0] * x) + a.ih[2];
+    const double Y = fma(a.ih[4], y, a.ih[3] * x) + a.ih[5];
+    const double W = fma(a.ih[7], y, a.ih[6] * x) + a.ih[8];
+    const double sx = X / W, sy = Y / W;
+    const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
+    if (!((xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1))) return 0u;   // -> texel (0,0), blanked
+    const uint32_t off = ((uint32_t)yi * (uint32_t)a.src_w + (uint32_t)xi) * 3u;
+    const uint32_t img_bytes = (uint32_t)a.src_h * (uint32_t)a.src_w * 3u;
+    if (off + 4u <= img_bytes) return ld4(simg + off) & 0xFFFFFFu;
+    return simg[off] | (simg[off + 1] << 8) | (simg[off + 2] << 16);
+}
+
+// 4 RGBX texels -> 12 packed bytes, stored whole or (ragged row) from local pixel `first` on
+__device__ __forceinline__ void nn_store(const uint32_t (&t)[FP_PX], unsigned char* drow, bool store_any, int first) {
+    if (!store_any) return;
+    if (first <= 0) {
+        pk3 w;
+        w.a = (t[0] & 0xFFFFFFu) | (t[1] << 24);
+        w.b = ((t[1] >> 8) & 0xFFFFu) | (t[2] << 16);
+        w.c = ((t[2] >> 16) & 0xFFu) | (t[3] << 8);
+        __builtin_memcpy(drow, &w, 12);
+    } else {
+#pragma unroll
+        for (int j = 1; j < FP_PX; ++j)
+            if (j >= first) { drow[3 * j] = (unsigned char)t[j]; drow[3 * j + 1] = (unsigned char)(t[j] >> 8); drow[3 * j + 2] = (unsigned char)(t[j] >> 16); }
+    }
+}
+
+template <int LOG_PW>
+__global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
+    constexpr int PW = 1 << LOG_PW, PH = 512 / PW, LPR = PW / 8, WX = 128 / PW;
+    constexpr double MAGIC_R = MAGIC + 0.5;                 // hi(s + MAGIC_R) - MAGIC_HI = floor(s + 0.5)
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * F8_CHUNKS];
+
+    const unsigned b = blockIdx.x;
+    const unsigned logical = (b & 7u) * a.cpx + (b >> 3);
+    if (logical >= a.nblocks) return;
+    const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;
+    const unsigned tx = logical - t * a.tiles_x;
+    const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
+    const unsigned ty = t - img * a.tiles_y;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int prow = lane / LPR, pq = lane % LPR;
+    const int wave_x = (wave % WX) * PW, wave_y = (wave / WX) * PH;
+    const int rr_raw = (int)ty * 16 + wave_y + prow;
+    const int rr = min(rr_raw, a.rows - 1);
+    const int tcol0 = (int)tx * 128, tcol = min(tcol0, a.out_w - 128), tshift = tcol0 - tcol;
+    const int lcol = wave_x + pq * 4, c0p = tcol + lcol;
+    const bool store_any = rr_raw < a.rows;
+    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;
+    unsigned char* drow = a.dst + (long long)img * a.dst_img_stride + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * 3u;
+    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+    const int out_row = a.row_begin + rr;
+
+    const double fr = (double)out_row, fc = (double)c0p;
+    const double X0 = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
+    const double Y0 = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
+    const double W0 = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+    uint32_t ehx[2], ehy[2], elx[2], ely[2];
+    bool wpos;
+    {
+        const double X7 = X0 + a.dxs8[6][0], Y7 = Y0 + a.dxs8[6][1], W7 = W0 + a.dxs8[6][2];
+        double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
+        double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
+        const double ux0 = fma(X0, r0, MAGIC_R), uy0 = fma(Y0, r0, MAGIC_R), ux7 = fma(X7, r7, MAGIC_R), uy7 = fma(Y7, r7, MAGIC_R);
+        ehx[0] = hi32(ux0); elx[0] = lo32(ux0); ehy[0] = hi32(uy0); ely[0] = lo32(uy0);
+        ehx[1] = hi32(ux7); elx[1] = lo32(ux7); ehy[1] = hi32(uy7); ely[1] = lo32(uy7);
+        const int h0 = (int)hi32(W0), h7 = (int)hi32(W7);
+        wpos = __all((int)(h0 > 0x2D300000) & (int)(h0 < 0x52B00000) & (int)(h7 > 0x2D300000) & (int)(h7 < 0x52B00000));
+    }
+    uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
+    auto run_coords = [&](const int h) {                    // only called when wpos holds (staged waves)
+        double X[3], Y[3], W[3], rc[3];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + a.dxs8[3 * h + j][0]; Y[j] = Y0 + a.dxs8[3 * h + j][1]; W[j] = W0 + a.dxs8[3 * h + j][2]; }
+        const double p12 = W[0] * W[1], P = p12 * W[2];
+        double rp = __builtin_amdgcn_rcp(P);
+        rp = fma(fma(-P, rp, 1.0), rp, rp);
+        const double r12 = rp * W[2];
+        rc[2] = rp * p12; rc[0] = r12 * W[1]; rc[1] = r12 * W[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double ux = fma(X[j], rc[j], MAGIC_R), uy = fma(Y[j], rc[j], MAGIC_R);
+            const int q = j + 1 - h;
+            hx[q] = hi32(ux); lx[q] = lo32(ux); hy[q] = hi32(uy); ly[q] = lo32(uy);
+        }
+        hx[3 * h] = ehx[h]; lx[3 * h] = elx[h]; hy[3 * h] = ehy[h]; ly[3 * h] = ely[h];
+    };
+
+    const int x0 = (int)__builtin_amdgcn_readlane(ehx[0], 0), x1 = (int)__builtin_amdgcn_readlane(ehx[1], LPR - 1);
+    const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
+    const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
+    const int hxmn = __builtin_amdgcn_readfirstlane(min(min(x0, x1), min(x2, x3))), hxmx = __builtin_amdgcn_readfirstlane(max(max(x0, x1), max(x2, x3)));
+    const int hymn = __builtin_amdgcn_readfirstlane(min(min(y0, y1), min(y2, y3))), hymx = __builtin_amdgcn_readfirstlane(max(max(y0, y1), max(y2, y3)));
+    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
+    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    // footprint rows ymn..ymx, texels xmn..xmx (a corner within NN_TIE of a boundary may really round one further:
+    // such pixels never use the slab); one row of slack below for the 9 bytes a chunk may read past its last texel
+    const int nrows = ymx - ymn + 1, C = (xmx - xmn + 4) >> 2;
+    const int total = nrows * C;
+    const bool staged = wpos & (xmn >= 0) & (xmx <= a.bound_w - 1) & (ymn >= 0) & (ymx <= min(a.bound_h - 1, a.src_h - 2)) &
+                        (nrows <= F8_CHUNKS) & (C <= F8_CHUNKS / 4) & (total <= F8_CHUNKS);
+
+    if (!staged) {                                          // every pixel by the reference's formula
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            uint32_t tex[FP_PX];
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) tex[j] = nn_exact_texel(a, simg, out_row, c0p + (PW / 2) * h + j);
+            const int first = tshift - (lcol + (PW / 2) * h);
+            nn_store(tex, drow + 3 * (PW / 2) * h, store_any & (first < 4), first);
+        }
+        return;
+    }
+
+    pk3 v[F8_PASSES];
+    {
+        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f * __builtin_amdgcn_rcpf((float)C))) + 1u;
+        const uint32_t last = (uint32_t)total - 1u;
+#pragma unroll
+        for (int p = 0; p < F8_PASSES; ++p) {
+            if (64 * p < total) {
+                const uint32_t i = min((uint32_t)(lane + 64 * p), last);
+                const uint32_t row = mul24(i, m) >> 16, col = i - mul24_s(row, (uint32_t)C);
+                __builtin_memcpy(&v[p], gbase + (size_t)mad24_s(row, pitch, mul24_12(col)), 12);
+            }
+        }
+    }
+    unsigned char* my = slab[wave];
+#pragma unroll
+    for (int p = 0; p < F8_PASSES; ++p) {
+        if (64 * p < total && lane + 64 * p < total) {
+            uint4 t4;
+            t4.x = v[p].a;
+            t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
+            t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
+            t4.w = v[p].c >> 8;
+            *reinterpret_cast<uint4*>(my + 16 * (lane + 64 * p)) = t4;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const uint32_t lpitch = 16u * (uint32_t)C;
+    const uint32_t slab_off = (uint32_t)wave * (16u * F8_CHUNKS);
+    const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        run_coords(h);
+        uint32_t tex[FP_PX];
+        bool tie[FP_PX], any_tie = false;
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            // fraction within NN_TIE of 0 (mod 1): lo + NN_TIE wraps below 2*NN_TIE
+            tie[j] = (lx[j] + NN_TIE < 2u * NN_TIE) | (ly[j] + NN_TIE < 2u * NN_TIE);
+            any_tie |= tie[j];
+            // a tie pixel's rounded index may lie one outside the footprint: keep its (unused) slab read in range
+            const uint32_t lo = tie[j] ? slab_off : mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
+            tex[j] = *reinterpret_cast<const uint32_t*>(&slab[0][0] + lo);
+        }
+        if (__any(any_tie)) {
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j)
+                if (tie[j]) tex[j] = nn_exact_texel(a, simg, out_row, c0p + (PW / 2) * h + j);
+        }
+        const int first = tshift - (lcol + (PW / 2) * h);
+        nn_store(tex, drow + 3 * (PW / 2) * h, store_any & (first < 4), first);
     }
 }
 

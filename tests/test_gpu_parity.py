@@ -643,6 +643,53 @@ def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
         assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (block, case, shape, int((d > 1).sum()), float((d != 0).mean()))
 
 
+def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
+    """homography.py:166-179 with the nearest-neighbour interpolator on an arbitrary output grid."""
+    from oracle import rwh_oracle as orc
+    xv, yv = np.meshgrid(xs, ys)
+    z = np.dstack([xv, yv, np.ones(xv.shape)]).reshape([xv.size, 3]).T
+    z_t = inv_h @ z
+    z_t /= z_t[-1, :]
+    return orc.nearest_neighbor(z_t, img.copy(), bound_hw[0], bound_hw[1], len(ys), len(xs))
+
+
+@pytest.mark.parametrize("exact", [False, True])
+@pytest.mark.parametrize("case", ["mild", "integer_ties", "rot12", "rot45", "persp", "zoom_out", "horizon"])
+def test_nearest_fast_kernel_bit_exact(gpu, case, exact, monkeypatch):
+    """The LDS-staged nearest-neighbour kernel (outputs >= 128 px wide, RGB u8) against the oracle, every pixel equal:
+    half-integer ties (an integer translation puts EVERY coordinate on x.5 after the +0.5), rotations that change the
+    patch shape, perspective, waves that gather (zoom-out), a horizon inside the output, ragged tiles, all shapes."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(77)
+    img = rng.integers(0, 256, (301, 433, 3), dtype=np.uint8)
+
+    def rot(deg, sc=1.0):
+        t = np.deg2rad(deg)
+        c, s, cx, cy = sc * np.cos(t), sc * np.sin(t), 216.0, 150.0
+        return np.array([[c, -s, cx - c * cx + s * cy], [s, c, cy - s * cx - c * cy], [0, 0, 1.0]])
+    H = {"mild": np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]]),
+         "integer_ties": np.array([[1.0, 0, 7.5], [0, 1.0, -3.5], [0, 0, 1.0]]),   # coordinates k + 0.5: trunc(s + 0.5) ties
+         "rot12": rot(12, 1.05), "rot45": rot(45, 0.9),
+         "persp": np.array([[0.9, 0.2, 11.0], [-0.15, 1.1, 30.0], [3e-4, -2e-4, 1.0]]),
+         "zoom_out": np.array([[0.4, 0, 20.0], [0, 0.45, 10.0], [0, 0, 1.0]]),
+         "horizon": np.linalg.inv(np.array([[1.0, 0.02, 3.0], [0.01, 1.0, 2.0], [-3.1e-3, -2.3e-3, 1.0]]))}[case]
+    inv = np.linalg.inv(H)
+    xs, ys = np.linspace(-9, 470, 480), np.linspace(-5, 325, 331)
+    grid = kernels.Grid(-9, 470, 480, -5, 325, 331)
+    ref = _oracle_nn_on_grid(img, inv, xs, ys, (301, 433))
+    src = torch.from_numpy(img).to(gpu)
+    for shape in ("5", "6", "7", None):
+        if shape is None:
+            monkeypatch.delenv("RWH_WARP_SHAPE", raising=False)
+        else:
+            monkeypatch.setenv("RWH_WARP_SHAPE", shape)
+        got = kernels.warp_backward(src, inv, grid, (301, 433), "nn", torch.uint8, exact=exact).cpu().numpy()
+        bad = int((got != ref).any(axis=2).sum())
+        assert bad == 0, (case, shape, exact, bad)
+    part = kernels.warp_backward(src, inv, grid, (301, 433), "nn", torch.uint8, rows=(37, 200), exact=exact).cpu().numpy()
+    assert np.array_equal(part, ref[37:200])
+
+
 # ------------------------------------------------------------------------------------------------
 # Exact mode (RWH_WARP_EXACT): bit-identical float64 / uint8 results
 # ------------------------------------------------------------------------------------------------

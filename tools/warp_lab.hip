@@ -176,7 +176,7 @@ int main(int argc, char** argv) {
         std::vector<Case> cases = {
             {"generic u8 (reference order)", [&] { return call(RWH_BILINEAR, RWH_U8, true); }},
             {"fast u8 (C ABI default)", [&] { return call(RWH_BILINEAR, RWH_U8, false); }},
-            {"nearest u8 (C ABI, generic kernel)", [&] { return call(RWH_NEAREST, RWH_U8, false); }},
+            {"nearest u8 (C ABI)", [&] { return call(RWH_NEAREST, RWH_U8, false); }},
             {"exact u8 (float64, RWH_WARP_EXACT)", [&] {
                 return rwh_warp_backward(src, SH, SW, 3, RWH_U8, (int64_t)src_bytes, B, ih, 1, G.x0, 1.0, G.x0 + G.w - 1, G.y0, 1.0,
                                          G.y0 + G.h - 1, G.h, G.w, SH, SW, RWH_BILINEAR, dst, RWH_U8, (int64_t)G.w * G.h * 3, 0, G.h, RWH_WARP_EXACT, nullptr); }},
