@@ -605,6 +605,16 @@ def test_warp_patch_shapes_vs_oracle(gpu, case, shape, monkeypatch):
     assert np.array_equal(part, u8[100:229])
 
 
+def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
+    """homography.py:166-179 with the nearest-neighbour interpolator on an arbitrary output grid."""
+    from oracle import rwh_oracle as orc
+    xv, yv = np.meshgrid(xs, ys)
+    z = np.dstack([xv, yv, np.ones(xv.shape)]).reshape([xv.size, 3]).T
+    z_t = inv_h @ z
+    z_t /= z_t[-1, :]
+    return orc.nearest_neighbor(z_t, img.copy(), bound_hw[0], bound_hw[1], len(ys), len(xs))
+
+
 @pytest.mark.parametrize("block", range(4))
 def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
     """Random homographies (rotation, anisotropic scale 0.6-1.8, shear, perspective, translation), random source and
@@ -641,16 +651,10 @@ def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
         u8 = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8).cpu().numpy()
         d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
         assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (block, case, shape, int((d > 1).sum()), float((d != 0).mean()))
-
-
-def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
-    """homography.py:166-179 with the nearest-neighbour interpolator on an arbitrary output grid."""
-    from oracle import rwh_oracle as orc
-    xv, yv = np.meshgrid(xs, ys)
-    z = np.dstack([xv, yv, np.ones(xv.shape)]).reshape([xv.size, 3]).T
-    z_t = inv_h @ z
-    z_t /= z_t[-1, :]
-    return orc.nearest_neighbor(z_t, img.copy(), bound_hw[0], bound_hw[1], len(ys), len(xs))
+        # nearest neighbour: every pixel equal (index work is bit-exact)
+        nn_ref = _oracle_nn_on_grid(img, inv, xs, ys, (sh, sw))
+        nn = kernels.warp_backward(src, inv, grid, (sh, sw), "nn", torch.uint8).cpu().numpy()
+        assert np.array_equal(nn, nn_ref), (block, case, shape, int((nn != nn_ref).any(axis=2).sum()))
 
 
 @pytest.mark.parametrize("exact", [False, True])
