@@ -156,6 +156,32 @@ def main():
     mpix_step = B * out_h * out_w / 1e6
     value = world * mpix_step * args.steps / elapsed
 
+    # ---- the other kernels of the warp entry point on the same workload (informational, N = 1) -----------------------
+    other = {}
+    if world == 1:
+        for name, interp, dt, out_bytes in (("nearest_u8", "nn", torch.uint8, 3), ("bilinear_f32_out", "bilinear", torch.float32, 12)):
+            nb = min(B, 16)
+            d2 = torch.empty((nb, out_h, out_w, 3), dtype=dt, device=dev)
+            s2 = src[:nb]
+
+            def step2():
+                kernels.warp_backward(s2, inv, grid, (SRC_H, SRC_W), interp, dt, zero_origin=False, out=d2)
+
+            for _ in range(20):
+                step2()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                step2()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 20
+            byt = nb * (3 * SRC_H * SRC_W + out_bytes * out_h * out_w)
+            other[name] = {"mpix_per_s": round(nb * out_h * out_w / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "frames": nb,
+                           "achieved_GBps": round(byt / ms / 1e6, 1), "frac_of_hbm_peak": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
+            del d2
+
     # ---- RANSAC workload -----------------------------------------------------------------------
     # BASELINE config 3 is K = 10 000 on matchespoints; one run costs ~80 us of launch + 16-byte readback latency on
     # this system whatever K is, so K = 100 000 (config 5's size) is reported beside it.  N > 1: the hypothesis range
@@ -292,6 +318,8 @@ def main():
             "ransac": dict(ransac_report, correspondences=185,
                            includes="K1 (also clears the keys) + K2 + argmax pass%s + 16-byte readback per run" % (" + all-reduce(max)" if world > 1 else "")),
         }
+        if other:
+            line["other_warp_kernels"] = other
         if config4:
             line["config4_panorama_8k"] = config4
         if not args.no_cpu and world == 1:
