@@ -435,7 +435,7 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     if (src_h < 3 || src_w < 3) return RWH_E_UNSUPPORTED;
     if (bound_h <= 0 || bound_w <= 0) return RWH_E_INVALID;
     if (interp != RWH_NEAREST && interp != RWH_BILINEAR) return RWH_E_INVALID;
-    if (n_h != 1) return RWH_E_UNSUPPORTED;
+    if (n_h != 1 && n_h != batch) return RWH_E_INVALID;
     if (channels != 3 && channels != 4) return RWH_E_UNSUPPORTED;
     if (src_dtype != RWH_U8 && src_dtype != RWH_F32) return RWH_E_UNSUPPORTED;
     const size_t esz = src_dtype == RWH_U8 ? 1 : 4;
@@ -447,6 +447,20 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
                            const_cast<unsigned char*>(static_cast<const unsigned char*>(d_src)), (long long)src_image_stride,
                            batch, (int)(channels * esz));
         if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
+    }
+
+    if (n_h == batch && batch > 1) {
+        // one homography per image: one launch per image on the same stream (the kernels take their coefficients as
+        // launch arguments; a per-image table in one launch is a later optimisation -- DESIGN.md section 7)
+        for (int i = 0; i < batch; ++i) {
+            const int st = rwh_warp_backward(static_cast<const unsigned char*>(d_src) + (int64_t)i * src_image_stride, src_h, src_w,
+                                             channels, src_dtype, src_image_stride, 1, inv_h + 9 * i, 1, x0, step_x, x_last, y0,
+                                             step_y, y_last, out_h, out_w, bound_h, bound_w, interp,
+                                             static_cast<unsigned char*>(d_dst) + (int64_t)i * dst_image_stride, dst_dtype,
+                                             dst_image_stride, row_begin, row_end, flags & ~RWH_WARP_ZERO_ORIGIN, stream);
+            if (st != RWH_OK) return st;
+        }
+        return RWH_OK;
     }
 
     WarpArgs a;

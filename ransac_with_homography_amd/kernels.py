@@ -49,7 +49,8 @@ class Grid:
 def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=True, rows=None, out=None, exact=False):
     """Launch K3.  `src`: [B,H,W,C] or [H,W,C] uint8/float32 GPU tensor.
     Returns a tensor [B,rows,out_w,C] (or without B) of `out_dtype` holding
-    output rows `rows=(begin,end)` (default: all).  `exact=True` selects the float64 kernel that
+    output rows `rows=(begin,end)` (default: all).  `inv_h`: inv(H) 3x3 for the whole batch, or [B,3,3] with one
+    inverse per image (same output grid for all).  `exact=True` selects the float64 kernel that
     reproduces the reference's arithmetic bit for bit (out_dtype float64 / uint8 for bilinear)."""
     lib = _lib.load()
     _dev_check(src)
@@ -65,10 +66,13 @@ def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=Tru
     else:
         _dev_check(out)
         assert out.dtype == out_dtype and out.numel() == B * (r1 - r0) * grid.out_w * C
-    ih = np.ascontiguousarray(inv_h, dtype=np.float64).reshape(9)
+    ih = np.ascontiguousarray(inv_h, dtype=np.float64)
+    n_h = 1 if ih.size == 9 else ih.size // 9          # one inverse for the batch, or [B,3,3]: one per image
+    assert ih.size == 9 * n_h and n_h in (1, B), "inv_h: 3x3, or one 3x3 per image of the batch"
+    ih = ih.reshape(9 * n_h)
     st = lib.rwh_warp_backward(
         _ptr(src), H, W, C, _DTYPE[src.dtype], src.stride(0) * src.element_size(), B,
-        ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), 1,
+        ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n_h,
         grid.x0, grid.step_x, grid.x_last, grid.y0, grid.step_y, grid.y_last,
         grid.out_h, grid.out_w, int(bound_hw[0]), int(bound_hw[1]), INTERP[interp],
         _ptr(out), _DTYPE[out_dtype], (r1 - r0) * grid.out_w * C * out.element_size(),

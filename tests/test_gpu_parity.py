@@ -524,6 +524,14 @@ def test_config5_batch_1080p(gpu):
     # nearest-neighbour batch path too
     nn = kernels.warp_backward(src, inv, grid, (1080, 1920), "nn", torch.uint8)
     assert torch.equal(kernels.warp_backward(src[5].contiguous(), inv, grid, (1080, 1920), "nn", torch.uint8), nn[5])
+    # one homography per image (n_h == batch): every image equals its own single-image warp
+    rng = np.random.default_rng(8)
+    invs = np.stack([np.linalg.inv(np.array([[np.cos(t), -np.sin(t), 30 * t], [np.sin(t), np.cos(t), 5.0], [1e-5 * i, 0, 1.0]]))
+                     for i, t in enumerate(rng.uniform(-0.3, 0.3, src.shape[0]))])
+    for interp, dt in (("bilinear", torch.uint8), ("nn", torch.uint8), ("bilinear", torch.float32)):
+        per = kernels.warp_backward(src, invs, grid, (1080, 1920), interp, dt)
+        for i in (0, 3, src.shape[0] - 1):
+            assert torch.equal(per[i], kernels.warp_backward(src[i].contiguous(), invs[i], grid, (1080, 1920), interp, dt)), (interp, i)
 
 
 def _oracle_warp_on_grid(img, inv_h, xs, ys, bound_hw):
