@@ -16,6 +16,7 @@
 //   * no MFMA: there is no dense contraction in this path.
 #include "rwh_common.h"
 #include <cstdlib>
+#include <vector>
 #include "rwh_warp_rgb8.h"
 
 namespace rwh {
@@ -333,7 +334,9 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // qualifies if its source footprints fit the LDS slab (nearly) everywhere.  64 x 8 is the default (measured 2-3 % ahead
 // of 128 x 4 on axis-aligned warps: fewer staged chunks per pixel); another qualifying shape replaces it only if its
 // staging loads touch clearly fewer 128-byte lines (a 64 x 8 patch rotated by 90 degrees "fits", but as 66 rows of 10
-// texels).  RWH_WARP_SHAPE=5|6|7 in the environment overrides (tests, lab).
+// texels).  The choice is a function of the homography and the WHOLE output grid only -- never of the row shard or the
+// batch -- so that shards, batches and single launches of the same warp run the same arithmetic and agree bit for bit.
+// RWH_WARP_SHAPE=5|6|7 in the environment overrides (tests, lab).
 static int choose_shape(const FastArgs& a) {
     if (const char* e = getenv("RWH_WARP_SHAPE")) {
         const int v = atoi(e);
@@ -348,7 +351,7 @@ static int choose_shape(const FastArgs& a) {
         double lines_sum = 0;
         for (int i = 0; i < 5; ++i)
             for (int j = 0; j < 5; ++j) {
-                const double r = (a.rows > ph ? (a.rows - ph) * (i / 4.0) : 0.0), c = (a.out_w > pw ? (a.out_w - pw) * (j / 4.0) : 0.0);
+                const double r = (a.out_h > ph ? (a.out_h - ph) * (i / 4.0) : 0.0), c = (a.out_w > pw ? (a.out_w - pw) * (j / 4.0) : 0.0);
                 long long ch; double ln;
                 if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &ch, &ln)) continue;   // horizon: gathers anyway
                 ++seen; fit += ch <= F8_CHUNKS; lines_sum += ln;
@@ -360,63 +363,115 @@ static int choose_shape(const FastArgs& a) {
     return best ? best : 7;   // nothing fits (strong zoom-out): every wave gathers; 128 x 4 has the longest stores
 }
 
-// Fast-path launch (RGB u8, bilinear): returns RWH_E_UNSUPPORTED when the shape needs the generic kernel.
-// variant: 0 = 4 px per lane (256 x 4 block tiles), 1 = 8 px per lane (128 x 16 block tiles, patch shape chosen here).
+// Coefficients of one homography on one output grid: X = cx[0] + row*cx[1] + col*cx[2] etc.
+static void fill_coef(Coef& c, const double* ih, double x0, double step_x, double y0, double step_y) {
+    c.cx[0] = ih[0] * x0 + ih[1] * y0 + ih[2]; c.cx[1] = ih[1] * step_y; c.cx[2] = ih[0] * step_x;
+    c.cy[0] = ih[3] * x0 + ih[4] * y0 + ih[5]; c.cy[1] = ih[4] * step_y; c.cy[2] = ih[3] * step_x;
+    c.cw[0] = ih[6] * x0 + ih[7] * y0 + ih[8]; c.cw[1] = ih[7] * step_y; c.cw[2] = ih[6] * step_x;
+    for (int i = 0; i < 9; ++i) c.ih[i] = ih[i];
+    c.image = 0;
+}
+
+// Column offsets of a lane's pixels in the 8 px kernel: two runs PW/2 apart, pixels of a run 1 column apart (uint8
+// output) or PW/8 columns apart (float32 output, rwh_warp_rgb8.h).
+static void fill_offsets(Coef& c, int shape, int pstr) {
+    for (int j = 1; j <= 7; ++j) {
+        const double o8 = (double)(j < 4 ? j * pstr : (1 << shape) / 2 + (j - 4) * pstr);
+        c.dxs8[j - 1][0] = o8 * c.cx[2]; c.dxs8[j - 1][1] = o8 * c.cy[2]; c.dxs8[j - 1][2] = o8 * c.cw[2];
+    }
+}
+
+// Fast-path launch (RGB u8; bilinear u8 / float32 output, or nearest): returns RWH_E_UNSUPPORTED when the shape needs
+// the generic kernel.
+// variant: 0 = 4 px per lane (256 x 4 block tiles), 1 = 8 px per lane (128 x 16 block tiles, patch shape chosen here),
+// 3 = nearest neighbour on the 8 px kernel's tiling.  n_h = 1: one homography for the batch; n_h = batch (variants 1
+// and 3): one per image, launched TAB_N images at a time with their coefficients as a second kernel argument.
 // (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on the 8 px kernel's 128 x 16 block tiles.)
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
                 int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
-                void (*custom)(const FastArgs) = nullptr) {
-    const bool px8 = variant >= 1, nn = variant == 3;       // 3: nearest neighbour on the 8 px kernel's tiling
+                void (*custom)(const FastArgs) = nullptr, int n_h = 1) {
+    const bool px8 = variant >= 1, nn = variant == 3;
     if (w.out_w < (px8 ? 128 : FP_PX) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
+    if (n_h != 1 && (!px8 || custom)) return RWH_E_UNSUPPORTED;
     const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
     if ((size_t)w.rows * (size_t)w.out_w * 3 * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
     FastArgs a;
     a.src = w.src; a.dst = w.dst; a.src_img_stride = w.src_img_stride; a.dst_img_stride = w.dst_img_stride;
-    a.cx[0] = ih[0] * x0 + ih[1] * y0 + ih[2]; a.cx[1] = ih[1] * step_y; a.cx[2] = ih[0] * step_x;
-    a.cy[0] = ih[3] * x0 + ih[4] * y0 + ih[5]; a.cy[1] = ih[4] * step_y; a.cy[2] = ih[3] * step_x;
-    a.cw[0] = ih[6] * x0 + ih[7] * y0 + ih[8]; a.cw[1] = ih[7] * step_y; a.cw[2] = ih[6] * step_x;
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
     a.row_begin = w.row_begin; a.rows = w.rows;
-    for (int i = 0; i < 9; ++i) a.ih[i] = ih[i];
     a.gx0 = w.x0; a.gstep_x = w.step_x; a.gx_last = w.x_last; a.gy0 = w.y0; a.gstep_y = w.step_y; a.gy_last = w.y_last;
     a.out_h = w.out_h;
-    const int shape = px8 ? choose_shape(a) : 0;
-    // column offsets of a lane's pixels: 1..3 (4 px kernel); 8 px kernel: two runs PW/2 apart, pixels of a run 1 column
-    // apart (uint8 output) or PW/8 columns apart (float32 output, rwh_warp_rgb8.h)
-    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << shape) / 8 : 1;
-    for (int j = 1; j <= 7; ++j) {
-        const double o4 = (double)j, o8 = (double)(j < 4 ? j * pstr : (px8 ? (1 << shape) / 2 : 4) + (j - 4) * pstr);
-        for (int q = 0; q < 3; ++q) {
-            const double c = q == 0 ? a.cx[2] : q == 1 ? a.cy[2] : a.cw[2];
-            a.dxs8[j - 1][q] = o8 * c;
-            if (j <= 3) a.dxs[j - 1][q] = o4 * c;
+    // patch shape: the host's choice per homography; with one homography per image the images are grouped by shape
+    int shape = 0, shapes[3] = {0, 0, 0};
+    std::vector<int> shape_of(n_h > 1 ? n_h : 0);
+    if (px8) {
+        for (int i = 0; i < n_h; ++i) {
+            fill_coef(a.c, ih + 9 * i, x0, step_x, y0, step_y);
+            shape = choose_shape(a);
+            if (n_h > 1) { shape_of[i] = shape; shapes[shape - 5] = 1; }
         }
     }
+    fill_coef(a.c, ih, x0, step_x, y0, step_y);
+    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << shape) / 8 : 1;
+    if (px8) fill_offsets(a.c, shape, pstr);
+    for (int j = 1; j <= 3; ++j) { a.dxs[j - 1][0] = j * a.c.cx[2]; a.dxs[j - 1][1] = j * a.c.cy[2]; a.dxs[j - 1][2] = j * a.c.cw[2]; }
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
     __builtin_memcpy(&a.ymax_bits, &ym, 8);
     a.tiles_x = (unsigned)(px8 ? (w.out_w + 127) / 128 : (w.out_w + 255) / 256);
     a.group = group;   // free parameter of a tools/warp_lab custom kernel
     a.tiles_y = (unsigned)(px8 ? (w.rows + 15) / 16 : (w.rows + 3) / 4);
-    const unsigned long long nb = (unsigned long long)a.tiles_x * a.tiles_y * (unsigned)batch;
-    if (nb >= (1ull << 31) / 8) return RWH_E_UNSUPPORTED;
-    a.nblocks = (unsigned)nb;
-    a.cpx = (a.nblocks + 7u) / 8u;
-    a.tiles_x_magic = div_magic(a.tiles_x, nb);
-    a.tiles_y_magic = div_magic(a.tiles_y, nb / a.tiles_x + 1);
-    if ((a.tiles_x > 1 && !a.tiles_x_magic) || (a.tiles_y > 1 && !a.tiles_y_magic)) return RWH_E_UNSUPPORTED;
-    const dim3 grid(8u * a.cpx), block(256);
-    void (*kern)(const FastArgs) = custom;
-    if (!kern) {
-        const bool u8 = dst_dtype == RWH_U8;
-        if (nn) kern = shape == 7 ? warp_rgb8_nn<7> : shape == 6 ? warp_rgb8_nn<6> : warp_rgb8_nn<5>;
-        else if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
-        else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
-        else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
-        else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
+    const bool u8 = dst_dtype == RWH_U8;
+    const dim3 block(256);
+    auto geometry = [&](int count) {
+        const unsigned long long nb = (unsigned long long)a.tiles_x * a.tiles_y * (unsigned)count;
+        if (nb >= (1ull << 31) / 8) return false;
+        a.nblocks = (unsigned)nb;
+        a.cpx = (a.nblocks + 7u) / 8u;
+        a.tiles_x_magic = div_magic(a.tiles_x, nb);
+        a.tiles_y_magic = div_magic(a.tiles_y, nb / a.tiles_x + 1);
+        return !((a.tiles_x > 1 && !a.tiles_x_magic) || (a.tiles_y > 1 && !a.tiles_y_magic));
+    };
+    if (n_h == 1) {
+        if (!geometry(batch)) return RWH_E_UNSUPPORTED;
+        void (*kern)(const FastArgs) = custom;
+        if (!kern) {
+            if (nn) kern = shape == 7 ? warp_rgb8_nn<7> : shape == 6 ? warp_rgb8_nn<6> : warp_rgb8_nn<5>;
+            else if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
+            else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
+            else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
+            else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
+        }
+        hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a);
+        return check_launch();
     }
-    hipLaunchKernelGGL(kern, grid, block, 0, s, a);
-    return check_launch();
+    // one homography per image: per shape, TAB_N images per launch with their coefficients as a second kernel argument
+    for (int sh = 7; sh >= 5; --sh) {
+        if (!shapes[sh - 5]) continue;
+        const int ps = u8 ? 1 : (1 << sh) / 8;
+        void (*kern)(const FastArgs, const CoefTab);
+        if (nn) kern = sh == 7 ? warp_rgb8_nn_tab<7> : sh == 6 ? warp_rgb8_nn_tab<6> : warp_rgb8_nn_tab<5>;
+        else if (sh == 7) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 7> : warp_rgb8_fast8_tab<float, 7>;
+        else if (sh == 6) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 6> : warp_rgb8_fast8_tab<float, 6>;
+        else kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 5> : warp_rgb8_fast8_tab<float, 5>;
+        CoefTab tab;
+        int count = 0;
+        for (int i = 0; i <= n_h; ++i) {
+            if (i < n_h && shape_of[i] == sh) {
+                fill_coef(tab.e[count], ih + 9 * i, x0, step_x, y0, step_y);
+                fill_offsets(tab.e[count], sh, ps);
+                tab.e[count++].image = i;
+            }
+            if (count == TAB_N || (i == n_h && count > 0)) {
+                for (int k = count; k < TAB_N; ++k) tab.e[k] = tab.e[0];
+                if (!geometry(count)) return RWH_E_UNSUPPORTED;
+                hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a, tab);
+                if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
+                count = 0;
+            }
+        }
+    }
+    return RWH_OK;
 }
 
 }  // namespace rwh
@@ -450,8 +505,25 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     }
 
     if (n_h == batch && batch > 1) {
-        // one homography per image: one launch per image on the same stream (the kernels take their coefficients as
-        // launch arguments; a per-image table in one launch is a later optimisation -- DESIGN.md section 7)
+        // one homography per image.  The staged RGB u8 kernels take a table of TAB_N coefficient sets per launch ...
+        const bool fast_bil = src_dtype == RWH_U8 && channels == 3 && interp == RWH_BILINEAR && !(flags & RWH_WARP_EXACT) &&
+                              (dst_dtype == RWH_U8 || dst_dtype == RWH_F32);
+        const bool fast_nn = src_dtype == RWH_U8 && channels == 3 && interp == RWH_NEAREST && dst_dtype == RWH_U8 &&
+                             (size_t)src_h * src_w * 3 < (1ull << 32) - 4;
+        if ((fast_bil || fast_nn) && out_w >= 128) {
+            WarpArgs a;
+            a.src = static_cast<const unsigned char*>(d_src);
+            a.dst = static_cast<unsigned char*>(d_dst);
+            a.src_img_stride = src_image_stride; a.dst_img_stride = dst_image_stride;
+            a.x0 = x0; a.step_x = step_x; a.x_last = x_last; a.y0 = y0; a.step_y = step_y; a.y_last = y_last;
+            a.src_h = src_h; a.src_w = src_w;
+            a.bound_h = bound_h < src_h ? bound_h : src_h;
+            a.bound_w = bound_w < src_w ? bound_w : src_w;
+            a.out_h = out_h; a.out_w = out_w; a.row_begin = row_begin; a.rows = row_end - row_begin;
+            const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, fast_nn ? 3 : 1, 1, nullptr, batch);
+            if (st != RWH_E_UNSUPPORTED) return st;
+        }
+        // ... every other configuration is one launch per image on the same stream
         for (int i = 0; i < batch; ++i) {
             const int st = rwh_warp_backward(static_cast<const unsigned char*>(d_src) + (int64_t)i * src_image_stride, src_h, src_w,
                                              channels, src_dtype, src_image_stride, 1, inv_h + 9 * i, 1, x0, step_x, x_last, y0,

@@ -49,23 +49,31 @@ constexpr int FP_LANES = 21;                           // staging lanes per sour
 constexpr int FP_TEXELS = 4 * FP_LANES;                // 84 texels per staged row
 constexpr int FP_PITCH = 4 * FP_TEXELS + 16;           // 352 B per staged row of RGBX texels (+16: bank stagger)
 
+// Per-homography coefficients.  One set travels inside FastArgs; launches with one homography per image carry a table
+// of them as a second kernel argument (CoefTab) and index it with the image number.
+struct Coef {
+    // X = cx[0] + row*cx[1] + col*cx[2] for output (row, col); likewise Y, W   (float64, host-built)
+    double cx[3], cy[3], cw[3];
+    double dxs8[7][3];                                   // 8 px kernel: column offsets of a lane's pixels x (cx[2], cy[2], cw[2])
+    double ih[9];                                        // inv(H), row major (nearest-neighbour kernel's exact formula)
+    long long image;                                     // table launches: index of this entry's image in the batch
+};
+constexpr int TAB_N = 8;                                 // images per launch when every image has its own homography
+struct CoefTab { Coef e[TAB_N]; };
+
 struct FastArgs {
     const unsigned char* src;
     unsigned char* dst;
     long long src_img_stride, dst_img_stride;            // bytes
-    // X = cx[0] + row*cx[1] + col*cx[2] for output (row, col); likewise Y, W   (float64, host-built)
-    double cx[3], cy[3], cw[3];
-    double dxs[3][3];                                    // dxs[j-1] = j * (cx[2], cy[2], cw[2])
-    double dxs8[7][3];                                   // 8 px kernel: column offsets 1, 2, 3, PW/2 .. PW/2+3 of the patch shape
+    Coef c;
+    double dxs[3][3];                                    // 4 px kernel: dxs[j-1] = j * (cx[2], cy[2], cw[2])
     unsigned long long xmax_bits, ymax_bits;             // bit patterns of MAGIC + (bound_w-1), MAGIC + (bound_h-1)
     int src_h, src_w, bound_h, bound_w, out_w;
     int row_begin, rows;                                 // produce output rows [row_begin, row_begin+rows)
     unsigned tiles_x, tiles_y, nblocks, cpx;
     unsigned tiles_x_magic, tiles_y_magic;               // floor(n/d) = umulhi(n, magic) for n < nblocks
     int group;                                           // free parameter of a tools/warp_lab custom kernel
-    // nearest-neighbour kernel only: the reference's own formula for the (rare) pixels it re-derives exactly
-    double ih[9];                                        // inv(H), row major
-    double gx0, gstep_x, gx_last, gy0, gstep_y, gy_last; // numpy.linspace output grid
+    double gx0, gstep_x, gx_last, gy0, gstep_y, gy_last; // numpy.linspace output grid (nearest-neighbour kernel's exact formula)
     int out_h;
 };
 
@@ -248,9 +256,9 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
     // ---- source coordinates of the lane's 4 pixels -----------------------------------------------
     const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
     double X[FP_PX], Y[FP_PX], W[FP_PX];
-    X[0] = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
-    Y[0] = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
-    W[0] = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+    X[0] = fma(fc, a.c.cx[2], fma(fr, a.c.cx[1], a.c.cx[0]));
+    Y[0] = fma(fc, a.c.cy[2], fma(fr, a.c.cy[1], a.c.cy[0]));
+    W[0] = fma(fc, a.c.cw[2], fma(fr, a.c.cw[1], a.c.cw[0]));
 #pragma unroll
     for (int j = 1; j < FP_PX; ++j) {
         X[j] = X[0] + a.dxs[j - 1][0];
@@ -426,7 +434,7 @@ constexpr int F8_CHUNKS = 64 * F8_PASSES;               // 384 chunks = 1536 tex
 // keeps it at 6 waves (LDS-limited).  The end pixels are computed once, so the footprint and the taps can never
 // disagree about a floor().
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastArgs a) {
+__device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
     constexpr int LPR = PW / 8;                             // lanes per patch row
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
@@ -440,6 +448,8 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     const unsigned tx = logical - t * a.tiles_x;
     const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
     const unsigned ty = t - img * a.tiles_y;
+    const Coef& co = tab ? tab[img] : a.c;                  // uniform: scalar loads either way
+    const unsigned img_mem = tab ? (unsigned)co.image : img;   // where the image lives in the batch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int prow = lane / LPR, pq = lane % LPR;             // patch row, 4-pixel column group within a half row
@@ -459,21 +469,21 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     const int c0p = tcol + lcol;
     const bool store_any = rr_raw < a.rows;
 
-    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;       // uniform
-    unsigned char* dimg = a.dst + (long long)img * a.dst_img_stride;              // uniform
+    const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;       // uniform
+    unsigned char* dimg = a.dst + (long long)img_mem * a.dst_img_stride;              // uniform
     // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
     DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
     const uint32_t pitch = (uint32_t)a.src_w * 3u;
 
     // ---- pixels 0 and 7 of the lane: own reciprocal ------------------------------------------------------------
     const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
-    const double X0 = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
-    const double Y0 = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
-    const double W0 = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+    const double X0 = fma(fc, co.cx[2], fma(fr, co.cx[1], co.cx[0]));
+    const double Y0 = fma(fc, co.cy[2], fma(fr, co.cy[1], co.cy[0]));
+    const double W0 = fma(fc, co.cw[2], fma(fr, co.cw[1], co.cw[0]));
     uint32_t ehx[2], ehy[2], elx[2], ely[2];                  // the lane's first and last pixel
     bool wpos;
     {
-        const double X7 = X0 + a.dxs8[6][0], Y7 = Y0 + a.dxs8[6][1], W7 = W0 + a.dxs8[6][2];
+        const double X7 = X0 + co.dxs8[6][0], Y7 = Y0 + co.dxs8[6][1], W7 = W0 + co.dxs8[6][2];
         double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
         double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
         const double ux0 = fma(X0, r0, MAGIC), uy0 = fma(Y0, r0, MAGIC), ux7 = fma(X7, r7, MAGIC), uy7 = fma(Y7, r7, MAGIC);
@@ -491,7 +501,7 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     auto run_coords = [&](const int h) {
         double X[3], Y[3], W[3], rc[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { X[j] = X0 + a.dxs8[3 * h + j][0]; Y[j] = Y0 + a.dxs8[3 * h + j][1]; W[j] = W0 + a.dxs8[3 * h + j][2]; }
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + co.dxs8[3 * h + j][0]; Y[j] = Y0 + co.dxs8[3 * h + j][1]; W[j] = W0 + co.dxs8[3 * h + j][2]; }
         const double p12 = W[0] * W[1], P = p12 * W[2];
         if (wpos) {                                                        // finite, normal product of positive W
             double rp = __builtin_amdgcn_rcp(P);
@@ -649,6 +659,12 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
     }
 }
 
+template <typename DstT, int LOG_PW>
+__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+// one homography per image: image i of the launch uses t.e[i]
+template <typename DstT, int LOG_PW>
+__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
 // The pixel index trunc(s + 0.5) is an INTEGER result, so "within 2^-32 px" is not good enough near a tie:
@@ -660,12 +676,12 @@ __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastA
 //     there, which floor() does not reproduce).
 constexpr uint32_t NN_TIE = 1u << 12;                   // 2^-20 px in units of 2^-32
 
-__device__ __forceinline__ uint32_t nn_exact_texel(const FastArgs& a, const unsigned char* simg, int r, int c) {
+__device__ __forceinline__ uint32_t nn_exact_texel(const FastArgs& a, const double (&ih)[9], const unsigned char* simg, int r, int c) {
     const double x = (c == a.out_w - 1) ? a.gx_last : (double)c * a.gstep_x + a.gx0;
     const double y = (r == a.out_h - 1) ? a.gy_last : (double)r * a.gstep_y + a.gy0;
-    const double X = fma(a.ih[1], y, a.ih[0] * x) + a.ih[2];
-    const double Y = fma(a.ih[4], y, a.ih[3] * x) + a.ih[5];
-    const double W = fma(a.ih[7], y, a.ih[6] * x) + a.ih[8];
+    const double X = fma(ih[1], y, ih[0] * x) + ih[2];
+    const double Y = fma(ih[4], y, ih[3] * x) + ih[5];
+    const double W = fma(ih[7], y, ih[6] * x) + ih[8];
     const double sx = X / W, sy = Y / W;
     const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
     if (!((xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1))) return 0u;   // -> texel (0,0), blanked
@@ -692,7 +708,7 @@ __device__ __forceinline__ void nn_store(const uint32_t (&t)[FP_PX], unsigned ch
 }
 
 template <int LOG_PW>
-__global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
+__device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW, LPR = PW / 8, WX = 128 / PW;
     constexpr double MAGIC_R = MAGIC + 0.5;                 // hi(s + MAGIC_R) - MAGIC_HI = floor(s + 0.5)
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * F8_CHUNKS];
@@ -704,6 +720,11 @@ __global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
     const unsigned tx = logical - t * a.tiles_x;
     const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
     const unsigned ty = t - img * a.tiles_y;
+    const Coef& co = tab ? tab[img] : a.c;
+    const unsigned img_mem = tab ? (unsigned)co.image : img;
+    double ih9[9];                                          // by value: a reference into the indexed table makes hipcc
+#pragma unroll                                              // copy the whole table to scratch
+    for (int i = 0; i < 9; ++i) ih9[i] = co.ih[i];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
     const int prow = lane / LPR, pq = lane % LPR;
@@ -713,19 +734,19 @@ __global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
     const int tcol0 = (int)tx * 128, tcol = min(tcol0, a.out_w - 128), tshift = tcol0 - tcol;
     const int lcol = wave_x + pq * 4, c0p = tcol + lcol;
     const bool store_any = rr_raw < a.rows;
-    const unsigned char* simg = a.src + (long long)img * a.src_img_stride;
-    unsigned char* drow = a.dst + (long long)img * a.dst_img_stride + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * 3u;
+    const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;
+    unsigned char* drow = a.dst + (long long)img_mem * a.dst_img_stride + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * 3u;
     const uint32_t pitch = (uint32_t)a.src_w * 3u;
     const int out_row = a.row_begin + rr;
 
     const double fr = (double)out_row, fc = (double)c0p;
-    const double X0 = fma(fc, a.cx[2], fma(fr, a.cx[1], a.cx[0]));
-    const double Y0 = fma(fc, a.cy[2], fma(fr, a.cy[1], a.cy[0]));
-    const double W0 = fma(fc, a.cw[2], fma(fr, a.cw[1], a.cw[0]));
+    const double X0 = fma(fc, co.cx[2], fma(fr, co.cx[1], co.cx[0]));
+    const double Y0 = fma(fc, co.cy[2], fma(fr, co.cy[1], co.cy[0]));
+    const double W0 = fma(fc, co.cw[2], fma(fr, co.cw[1], co.cw[0]));
     uint32_t ehx[2], ehy[2], elx[2], ely[2];
     bool wpos;
     {
-        const double X7 = X0 + a.dxs8[6][0], Y7 = Y0 + a.dxs8[6][1], W7 = W0 + a.dxs8[6][2];
+        const double X7 = X0 + co.dxs8[6][0], Y7 = Y0 + co.dxs8[6][1], W7 = W0 + co.dxs8[6][2];
         double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
         double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
         const double ux0 = fma(X0, r0, MAGIC_R), uy0 = fma(Y0, r0, MAGIC_R), ux7 = fma(X7, r7, MAGIC_R), uy7 = fma(Y7, r7, MAGIC_R);
@@ -738,7 +759,7 @@ __global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
     auto run_coords = [&](const int h) {                    // only called when wpos holds (staged waves)
         double X[3], Y[3], W[3], rc[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { X[j] = X0 + a.dxs8[3 * h + j][0]; Y[j] = Y0 + a.dxs8[3 * h + j][1]; W[j] = W0 + a.dxs8[3 * h + j][2]; }
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + co.dxs8[3 * h + j][0]; Y[j] = Y0 + co.dxs8[3 * h + j][1]; W[j] = W0 + co.dxs8[3 * h + j][2]; }
         const double p12 = W[0] * W[1], P = p12 * W[2];
         double rp = __builtin_amdgcn_rcp(P);
         rp = fma(fma(-P, rp, 1.0), rp, rp);
@@ -773,7 +794,7 @@ __global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
         for (int h = 0; h < 2; ++h) {
             uint32_t tex[FP_PX];
 #pragma unroll
-            for (int j = 0; j < FP_PX; ++j) tex[j] = nn_exact_texel(a, simg, out_row, c0p + (PW / 2) * h + j);
+            for (int j = 0; j < FP_PX; ++j) tex[j] = nn_exact_texel(a, ih9, simg, out_row, c0p + (PW / 2) * h + j);
             const int first = tshift - (lcol + (PW / 2) * h);
             nn_store(tex, drow + 3 * (PW / 2) * h, store_any & (first < 4), first);
         }
@@ -829,22 +850,27 @@ __global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) {
         if (__any(any_tie)) {
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j)
-                if (tie[j]) tex[j] = nn_exact_texel(a, simg, out_row, c0p + (PW / 2) * h + j);
+                if (tie[j]) tex[j] = nn_exact_texel(a, ih9, simg, out_row, c0p + (PW / 2) * h + j);
         }
         const int first = tshift - (lcol + (PW / 2) * h);
         nn_store(tex, drow + 3 * (PW / 2) * h, store_any & (first < 4), first);
     }
 }
 
-// Source footprint of a pw x ph output patch whose top-left pixel is (row r, column c) of the launch: chunks (12 B =
+template <int LOG_PW>
+__global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) { nn_body<LOG_PW>(a, nullptr); }
+template <int LOG_PW>
+__global__ __launch_bounds__(256) void warp_rgb8_nn_tab(const FastArgs a, const CoefTab t) { nn_body<LOG_PW>(a, t.e); }
+
+// Source footprint of a pw x ph output patch whose top-left pixel is (row r, column c) of the output grid: chunks (12 B =
 // 4 texels, what the slab has to hold) and an estimate of the 128-byte lines its staging loads touch.  Host-side twin
 // of the kernel's footprint arithmetic, used only to choose the patch shape.  false: W <= 0 at a corner.
 inline bool patch_footprint(const FastArgs& a, double r, double c, int pw, int ph, long long* chunks, double* lines) {
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     for (int k = 0; k < 4; ++k) {
-        const double rr = a.row_begin + r + (k & 2 ? ph - 1 : 0), cc = c + (k & 1 ? pw - 1 : 0);
-        const double X = a.cx[0] + rr * a.cx[1] + cc * a.cx[2], Y = a.cy[0] + rr * a.cy[1] + cc * a.cy[2];
-        const double W = a.cw[0] + rr * a.cw[1] + cc * a.cw[2];
+        const double rr = r + (k & 2 ? ph - 1 : 0), cc = c + (k & 1 ? pw - 1 : 0);   // rows of the whole output grid
+        const double X = a.c.cx[0] + rr * a.c.cx[1] + cc * a.c.cx[2], Y = a.c.cy[0] + rr * a.c.cy[1] + cc * a.c.cy[2];
+        const double W = a.c.cw[0] + rr * a.c.cw[1] + cc * a.c.cw[2];
         if (!(W > 0)) return false;
         const double x = __builtin_floor(X / W), y = __builtin_floor(Y / W);
         xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax; ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;

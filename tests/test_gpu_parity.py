@@ -197,6 +197,31 @@ def test_warp_4k_translation_and_linearity(gpu):
     assert torch.allclose(wa + wb, ws, rtol=1e-5, atol=1e-4)
 
 
+def test_warp_one_homography_per_image(gpu):
+    """n_h == batch: 19 images (more than two coefficient tables of 8, with a remainder), each with its own rotation /
+    perspective: every image of the batched call equals its own single-image call, for the staged bilinear (u8 and
+    float32 out) and nearest kernels, the exact kernel and a narrow output (the per-image launch fallback)."""
+    from ransac_with_homography_amd import kernels
+    g = torch.Generator(device="cpu").manual_seed(19)
+    src = torch.randint(0, 256, (19, 240, 352, 3), dtype=torch.uint8, generator=g).to(gpu)
+    rng = np.random.default_rng(19)
+    invs = []
+    for i in range(19):
+        t = rng.uniform(-0.8, 0.8)
+        H = np.array([[np.cos(t), -np.sin(t), rng.uniform(0, 60)], [np.sin(t), np.cos(t), rng.uniform(-30, 30)],
+                      [rng.uniform(-2e-4, 2e-4), rng.uniform(-2e-4, 2e-4), 1.0]])
+        invs.append(np.linalg.inv(H))
+    invs = np.stack(invs)
+    for (ow, oh) in ((400, 260), (100, 90)):
+        grid = kernels.Grid(-10, -10 + ow - 1, ow, -6, -6 + oh - 1, oh)
+        for interp, dt, exact in (("bilinear", torch.uint8, False), ("bilinear", torch.float32, False), ("nn", torch.uint8, False),
+                                  ("bilinear", torch.uint8, True)):
+            per = kernels.warp_backward(src, invs, grid, (240, 352), interp, dt, exact=exact)
+            for i in (0, 7, 8, 15, 16, 18):
+                one = kernels.warp_backward(src[i].contiguous(), invs[i], grid, (240, 352), interp, dt, exact=exact)
+                assert torch.equal(per[i], one), (ow, interp, dt, exact, i)
+
+
 def test_warp_8k_properties(gpu):
     """The north_star's 8K frame (7680x4320 RGB u8) through the fast kernels: an integer translation reproduces the
     source exactly (bilinear u8, bilinear float32 and nearest neighbour), a half-pixel shift is the exact average of two
