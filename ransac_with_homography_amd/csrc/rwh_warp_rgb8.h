@@ -179,28 +179,7 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][2], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][0], 1, q);
             q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][1], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][2], 3, q);
             w.c = q;
-#ifdef RWH_ABL_STORE_X4   // tools/warp_lab ablation hook: same bytes, but as aligned 16-byte stores (scrambled pixels)
-            {
-                const int lane_ = threadIdx.x & 63, pq_ = lane_ & 15;
-                // this half's 12 bytes belong to a 384-byte row segment starting 24*pq_ (+12 for the 2nd half) before drow
-                const bool second = (((size_t)drow / 12) & 1) != 0;   // crude: which half (timing only)
-                unsigned char* seg = reinterpret_cast<unsigned char*>(drow) - (second ? 12 : 0) - 24 * pq_;
-                if (!second && pq_ < 12) { *reinterpret_cast<uint4*>(seg + 32 * pq_) = uint4{w.a, w.b, w.c, w.a}; }
-                if (second && pq_ < 12) { *reinterpret_cast<uint4*>(seg + 32 * pq_ + 16) = uint4{w.a, w.b, w.c, w.b}; }
-            }
-#elif defined(RWH_STORE_NT) || defined(RWH_STORE_SC)
-            {   // tools/warp_lab experiment hook: cache-policy bits on the output store
-                typedef uint32_t u3 __attribute__((ext_vector_type(3)));
-                const u3 dv = {w.a, w.b, w.c};
-#ifdef RWH_STORE_NT
-                asm volatile("global_store_dwordx3 %0, %1, off nt" :: "v"(drow), "v"(dv) : "memory");
-#else
-                asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" :: "v"(drow), "v"(dv) : "memory");
-#endif
-            }
-#else
             __builtin_memcpy(drow, &w, 12);
-#endif
         } else {
 #pragma unroll
             for (int v = 0; v < 3; ++v) {
