@@ -40,6 +40,17 @@ def test_argument_validation_without_gpu(lib):
     assert lib.rwh_dlt4_batched(null, null, 10, null, 4, null, null, null) == -1
     assert lib.rwh_score_count(null, null, null, 10, 4, 5.0, 0, 3, 0, null, null, null, null, null) == -1
     assert lib.rwh_project_points(null, null, 10, 0, null, null) == -1
+    assert lib.rwh_ransac_search(null, null, 10, null, 4, 5.0, 0, 3, 0, null, null, null, null, null, 1, null) == -1
+    assert lib.rwh_ransac_batched(null, null, null, 2, 10, 4, null, 0, 0, 5.0, 0, null, null, null, null, null, null, 0, null) == -1
+    assert lib.rwh_stitch_panorama(null, 8, 8, null, 8, 8, ih, 0, 0, 8, 8, 0, 0, 0, 0, 8, 8, 0, 0.2, null, 0, null) == -1
+    # n_h must be 1 or the batch size; bad row ranges; an empty row shard is a no-op even with NULL buffers
+    one = ctypes.c_void_p(1)            # non-NULL, never dereferenced: validation comes first
+    st = lib.rwh_warp_backward(one, 10, 10, 3, 0, 300, 3, ih, 2, 0., 1., 9., 0., 1., 9., 10, 10, 10, 10, 1, one, 0, 300, 0, 10, 0, null)
+    assert st == -1
+    st = lib.rwh_warp_backward(one, 10, 10, 3, 0, 300, 1, ih, 1, 0., 1., 9., 0., 1., 9., 10, 10, 10, 10, 1, one, 0, 300, 5, 4, 0, null)
+    assert st == -1
+    st = lib.rwh_warp_backward(null, 10, 10, 3, 0, 300, 1, ih, 1, 0., 1., 9., 0., 1., 9., 10, 10, 10, 10, 1, null, 0, 300, 4, 4, 0, null)
+    assert st == 0
 
 
 def test_no_cpu_fallback():
