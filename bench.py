@@ -314,6 +314,8 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                          "traffic": traffic, "algorithmic_bytes_per_launch": alg_bytes,
                          "kernel_ms": round(kernel_ms, 4),
+                         "limiter": "VALU issue: 440 VALU instructions per 512-pixel wave, VALU active 81-84 % of the kernel "
+                                    "(rocprofv3 PMC, profiles/r01_pmc_valu.txt); HBM traffic = 1.0003 x algorithmic",
                          "read_only_frac": round(B * 3 * SRC_H * SRC_W / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
             "ransac": dict(ransac_report, correspondences=185,
                            includes="K1 (also clears the keys) + K2 + argmax pass%s + 16-byte readback per run" % (" + all-reduce(max)" if world > 1 else "")),
