@@ -103,6 +103,10 @@ __device__ __forceinline__ uint32_t shl2_add_s(uint32_t a, uint32_t c_uniform) {
     asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(r) : "v"(a), "s"(c_uniform));          //  alignbit + and + add otherwise)
     return r;
 }
+// min / max of wave-uniform integers on the scalar unit (left to itself, hipcc reduces the four footprint corners with
+// v_min3 / v_max3 plus the v_mov copies their operands need: a dozen VALU issues per wave)
+__device__ __forceinline__ int smin(int a, int b) { int r; asm("s_min_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
+__device__ __forceinline__ int smax(int a, int b) { int r; asm("s_max_i32 %0, %1, %2" : "=s"(r) : "s"(a), "s"(b) : "scc"); return r; }
 __device__ __forceinline__ uint32_t mul24_12(uint32_t a) {                          // inline constant
     uint32_t r;
     asm("v_mul_u32_u24 %0, %1, 12" : "=v"(r) : "v"(a));
@@ -281,10 +285,8 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
     const int x2 = (int)__builtin_amdgcn_readlane(hx[0], 48), x3 = (int)__builtin_amdgcn_readlane(hx[FP_PX - 1], 63);
     const int y0 = (int)__builtin_amdgcn_readlane(hy[0], 0), y1 = (int)__builtin_amdgcn_readlane(hy[FP_PX - 1], 15);
     const int y2 = (int)__builtin_amdgcn_readlane(hy[0], 48), y3 = (int)__builtin_amdgcn_readlane(hy[FP_PX - 1], 63);
-    const int xa = min(x0, x1), xb = min(x2, x3), xc = max(x0, x1), xd = max(x2, x3);
-    const int ya = min(y0, y1), yb = min(y2, y3), yc = max(y0, y1), yd = max(y2, y3);
-    const int hxmn = __builtin_amdgcn_readfirstlane(min(xa, xb)), hxmx = __builtin_amdgcn_readfirstlane(max(xc, xd));
-    const int hymn = __builtin_amdgcn_readfirstlane(min(ya, yb)), hymx = __builtin_amdgcn_readfirstlane(max(yc, yd));
+    const int hxmn = smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
+    const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
     // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row,
@@ -507,10 +509,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
     const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
     const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
-    const int xa = min(x0, x1), xb = min(x2, x3), xc = max(x0, x1), xd = max(x2, x3);
-    const int ya = min(y0, y1), yb = min(y2, y3), yc = max(y0, y1), yd = max(y2, y3);
-    const int hxmn = __builtin_amdgcn_readfirstlane(min(xa, xb)), hxmx = __builtin_amdgcn_readfirstlane(max(xc, xd));
-    const int hymn = __builtin_amdgcn_readfirstlane(min(ya, yb)), hymx = __builtin_amdgcn_readfirstlane(max(yc, yd));
+    const int hxmn = smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
+    const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
     // footprint: rows ymn..ymx+1, texels xmn..xmx+1, as nrows x C chunks of 4 texels
@@ -757,8 +757,8 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
     const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
     const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
-    const int hxmn = __builtin_amdgcn_readfirstlane(min(min(x0, x1), min(x2, x3))), hxmx = __builtin_amdgcn_readfirstlane(max(max(x0, x1), max(x2, x3)));
-    const int hymn = __builtin_amdgcn_readfirstlane(min(min(y0, y1), min(y2, y3))), hymx = __builtin_amdgcn_readfirstlane(max(max(y0, y1), max(y2, y3)));
+    const int hxmn = smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
+    const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
     // footprint rows ymn..ymx, texels xmn..xmx (a corner within NN_TIE of a boundary may really round one further:
