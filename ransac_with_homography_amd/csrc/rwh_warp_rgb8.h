@@ -131,12 +131,17 @@ __device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, floa
 // PSTR > 1 (float32 output of the 8 px kernel): the four pixels are PSTR columns apart, pixel j is stored (12 bytes)
 // at drow + 3*j*PSTR if j*PSTR >= shift -- neighbouring lanes then write neighbouring pixels in every store
 // instruction (four consecutive float32 pixels per lane = 48-byte lane stride cost 2.7x the time).
+// `xpose` (float32 output, PSTR > 1 only; wave-uniform, or nullptr): 48*PSTR bytes of LDS per lane group through which
+// the group's 4*PSTR pixels are re-dealt so that lane l stores the 16-byte pieces l, PSTR + l, 2*PSTR + l of the
+// group's contiguous 48*PSTR-byte row segment: three fully coalesced dwordx4 stores instead of four 12-byte ones
+// (the texture-address path, 87 % busy on this variant, charges a dwordx3 like a dwordx4).
 template <typename DstT, int PSTR = 1>
 __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                             const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                             const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
                                             const float (&wy0)[FP_PX], const float (&wy1)[FP_PX],
-                                            DstT* drow, bool store_any, int shift) {
+                                            DstT* drow, bool store_any, int shift, unsigned char* xpose = nullptr,
+                                            int group = 0, int l = 0) {
     constexpr bool U8 = sizeof(DstT) == 1;
     constexpr float BIAS = U8 ? U8_BIAS : 0.f;
     float o[FP_PX][3];
@@ -156,12 +161,33 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             o[j][k] = acc.x; o[j + 1][k] = acc.y;
         }
     }
-    if (!store_any) return;
+    if (!store_any && !xpose) return;
 #ifdef RWH_ABL_NOSTORE  // tools/warp_lab ablation hook (never defined in the product build)
     if (o[0][0] + o[1][1] + o[2][2] + o[3][0] != -12345.f) return;
 #endif
     if constexpr (PSTR > 1) {
         static_assert(!U8, "strided runs are the float32 layout");
+        if (xpose) {                                          // uniform; the caller guarantees shift == 0 for the wave
+            unsigned char* region = xpose + group * (48 * PSTR);
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const pk3 w = {__float_as_uint(o[j][0]), __float_as_uint(o[j][1]), __float_as_uint(o[j][2])};
+                __builtin_memcpy(region + 12 * (l + j * PSTR), &w, 12);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            unsigned char* seg = reinterpret_cast<unsigned char*>(drow) - 12 * l;   // the group's row segment
+#pragma unroll
+            for (int v = 0; v < 3; ++v) {
+                const uint4 piece = *reinterpret_cast<const uint4*>(region + 16 * (v * PSTR + l));
+                if (store_any) __builtin_memcpy(seg + 16 * (v * PSTR + l), &piece, 16);
+            }
+            // the next run's pieces go to the same region: its LDS writes queue behind these reads (in-order LDS)
+            __builtin_amdgcn_wave_barrier();
+            return;
+        }
+        if (!store_any) return;
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j)
             if (j * PSTR >= shift) {
@@ -589,8 +615,15 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
 #endif
             }
             const int first = tshift - (lcol + (PW / 2) * h);   // local pixels at columns >= first are this tile's
-            blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
-                                    store_any & (first <= 3 * PSTR), max(first, 0));
+            if constexpr (PSTR > 1) {
+                // float32 output: re-deal through the free upper half of the slab when there is one (uniform)
+                unsigned char* xp = (total <= F8_CHUNKS / 2 && tshift == 0) ? my + 16 * (F8_CHUNKS / 2) : nullptr;
+                blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                                        xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
+            } else {
+                blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                                        store_any & (first <= 3 * PSTR), max(first, 0));
+            }
         }
         return;
     }
