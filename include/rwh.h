@@ -52,6 +52,14 @@ RWH_API int rwh_abi_version(void);
 RWH_API const char* rwh_strerror(int code);
 
 /*
+ * Lab / test hook, not part of the data path: pins a launch heuristic process-wide (value 0 = back to the library's
+ * own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
+ * hypotheses per wavefront of the scorer (1..64).  Results never depend on either (tests/test_gpu_parity.py).
+ */
+enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1 };
+RWH_API int rwh_lab_tune(int knob, int value);
+
+/*
  * Backward perspective warp.  Replaces, per call, the body of
  *   wrapPerspective      homography.py:166-179  (grid -> inv(H) -> divide -> interpolate)
  *   wrapPerspectiveScan  homography.py:197-208
@@ -80,9 +88,9 @@ RWH_API const char* rwh_strerror(int code);
  * Supported: channels 3 or 4; src_dtype U8 or F32; dst_dtype == src_dtype for
  * RWH_NEAREST; dst_dtype U8 (truncating) or F32 for RWH_BILINEAR (F64 or U8 with RWH_WARP_EXACT).
  * n_h is 1 (one homography for the whole batch) or `batch` (inv_h holds batch
- * 3x3 matrices, image b uses the b-th; at most RWH_MAX_H_PER_CALL).
+ * 3x3 matrices, image b uses the b-th; any batch size -- the library launches
+ * groups of images that share a kernel configuration).
  */
-#define RWH_MAX_H_PER_CALL 1
 RWH_API int rwh_warp_backward(const void* d_src, int src_h, int src_w, int channels, int src_dtype,
                       int64_t src_image_stride, int batch,
                       const double* inv_h, int n_h,

@@ -17,9 +17,10 @@ RWH_WARP_ZERO_ORIGIN = 1
 RWH_WARP_EXACT = 2
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR = 1, 2
 RWH_BATCH_DEVICE_SAMPLING = 1
+RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW = 0, 1
 
 # every symbol include/rwh.h declares (tests check the library exports them all)
-EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_warp_backward", "rwh_dlt4_batched",
+EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_warp_backward", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama")
 
 
@@ -41,6 +42,8 @@ def _bind(lib):
     lib.rwh_abi_version.argtypes = []
     lib.rwh_strerror.restype = c.c_char_p
     lib.rwh_strerror.argtypes = [i32]
+    lib.rwh_lab_tune.restype = i32
+    lib.rwh_lab_tune.argtypes = [i32, i32]
     lib.rwh_warp_backward.restype = i32
     lib.rwh_warp_backward.argtypes = [vp, i32, i32, i32, i32, i64, i32,        # src, h, w, c, dtype, stride, batch
                                       c.POINTER(f64), i32,                    # inv_h, n_h

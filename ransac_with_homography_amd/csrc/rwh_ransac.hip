@@ -18,7 +18,6 @@
 //      'backward' does the same through inv(val) (float64 inverse rounded to float32).
 // No FMA contraction anywhere (rwh_common.h), no fast-math, IEEE divide / sqrt.
 #include "rwh_common.h"
-#include <cstdlib>
 
 namespace rwh {
 
@@ -55,9 +54,9 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     if (reset_keys && t < n_reset) reset_keys[t] = 0ull;
     if (blockIdx.x * 64 >= k) return;             // whole wave past the end
     const bool live = t < k;
-    if (!live) idx = nullptr;                     // lanes past the end compute on point 0 and store nothing
+    if (!live) idx = nullptr;                     // lanes past the end compute on point 0 of problem 0 and store nothing
     if (offsets) {
-        const int p = t / k_per;
+        const int p = live ? t / k_per : 0;       // (a dead lane's own t / k_per can lie past the offsets table)
         const int base = offsets[p];
         m = offsets[p + 1] - base;
         pa += 2 * (size_t)base; pb += 2 * (size_t)base;
@@ -510,7 +509,7 @@ extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const flo
     // hypotheses per wave: enough waves to fill the chip (>= ~8 per SIMD) before a wave gets more than one
     int hpw = k / (256 * 4 * 32);   // measured: 1 up to ~30 k hypotheses, 2-4 at 100 k (tools/k2time.py)
     hpw = hpw < 1 ? 1 : (hpw > 8 ? 8 : hpw);
-    if (const char* e = getenv("RWH_SCORE_HPW")) { const int v = atoi(e); if (v >= 1 && v <= 64) hpw = v; }  // tuning knob
+    if (g_force_score_hpw) hpw = g_force_score_hpw;   // lab override (rwh_lab_tune)
     const int waves = (k + hpw - 1) / hpw;
     const dim3 grid((waves + 3) / 4);
     const int words = (m + 63) / 64;

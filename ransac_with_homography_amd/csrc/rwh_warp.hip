@@ -336,12 +336,9 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // staging loads touch clearly fewer 128-byte lines (a 64 x 8 patch rotated by 90 degrees "fits", but as 66 rows of 10
 // texels).  The choice is a function of the homography and the WHOLE output grid only -- never of the row shard or the
 // batch -- so that shards, batches and single launches of the same warp run the same arithmetic and agree bit for bit.
-// RWH_WARP_SHAPE=5|6|7 in the environment overrides (tests, lab).
+// rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 5|6|7) overrides (tests, lab).
 static int choose_shape(const FastArgs& a) {
-    if (const char* e = getenv("RWH_WARP_SHAPE")) {
-        const int v = atoi(e);
-        if (v >= 5 && v <= 7) return v;
-    }
+    if (g_force_warp_shape) return g_force_warp_shape;
     int best = 0;
     double best_lines = 1e300;
     const int order[3] = {6, 7, 5};

@@ -19,13 +19,29 @@ generator exactly as k successive `np.random.randint(0, M, 4)` calls would
 (ransac.py:177), and the generator is left where the reference would leave it
 (an early exit at iteration e consumes only e+1 draws).
 
+Solver parity (ransac.py:177 draws WITH replacement; homography.py:81-87): a sample with a repeated
+index gives a rank-deficient 8 x 9 system, for which the reference still takes whatever null vector
+LAPACK's SVD returns and lets it compete for the running best; and on ill-conditioned samples K1's
+float64 elimination and LAPACK can round to neighbouring float32 H.  `_settle_on_host` therefore
+re-derives, with the reference's own arithmetic (float32 DLT matrix -> numpy.linalg.svd -> /h[8],
+the host branch of `calcHomography`), every hypothesis K1 flagged and every unflagged one whose
+count is within `RESCORE_MARGIN` of the best (or of the early-exit count), re-scores those rows with
+K2 (bit-exact given H) and only then applies the accept rules.  ~4 % of the samples at M = 185:
+about 40 SVDs (0.5 ms of host time) for k = 1000.
+
 There is no CPU implementation of the loop here: without librwh_hip.so and a GPU
 `RANSAC.run` raises `RwhUnavailable`.
 """
 import numpy as np
 
 from . import _lib, kernels
-from .homography import calcHomography, calcHomographyLinear, cylindericlMap, stitchPanorama  # noqa: F401
+from .homography import (_pair_rows, calcHomography, calcHomographyLinear, cylindericlMap,  # noqa: F401
+                         stitchPanorama)
+
+# An unflagged K1 hypothesis may differ from LAPACK's by float32 round-off on ill-conditioned samples; measured
+# effect on the inlier count: <= 2 on 6 of ~19 300 golden hypotheses (tests/test_gpu_parity.py).  Hypotheses whose
+# count is within this margin of a decision (the best count, the early-exit count) are re-derived on the host.
+RESCORE_MARGIN = 8
 
 LVL = 0
 
@@ -48,6 +64,75 @@ def _points_rows(P):
     """features x observations (2 x M or 3 x M) -> contiguous M x 2 float32."""
     P = np.asarray(P)
     return np.ascontiguousarray(P.T[:, :2], dtype=np.float32)
+
+
+def svd_hypotheses(pts_a, pts_b, idx_rows):
+    """The reference's 4-point solve (homography.py:4-14, 71-88) for n samples at once on the host:
+    float32 DLT matrices -> numpy.linalg.svd (LAPACK dgesdd, float64 inside, cast back to float32) ->
+    last right-singular vector / its 9th element.  The stacked call runs the same LAPACK routine per
+    matrix as n single calls (bit-identical, tests/test_oracle_golden.py).  -> float32 [n, 9]."""
+    idx_rows = np.asarray(idx_rows).reshape(-1, 4)
+    flat = idx_rows.reshape(-1)
+    mats = _pair_rows(pts_a[flat], pts_b[flat], -1).reshape(-1, 8, 9)
+    with np.errstate(all="ignore"):          # h[8] == 0 divides like the reference does (inf / nan rows score 0)
+        _, _, vt = np.linalg.svd(mats)
+        h = vt[:, -1, :]
+        return np.ascontiguousarray(h / h[:, 8:9])
+
+
+def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, method, margin, stats=None):
+    """Accept rules of ransac.py:186-202 over K1/K2's results, exact with respect to the reference's solver.
+
+    counts / flags: host copies of K2's counts and K1's flags for the k hypotheses of `idx_host`.  Hypotheses are
+    "settled" (H from the host SVD, count + mask from K2 on that H) in rounds until every hypothesis that can take
+    part in the decision is settled:
+      * nothing after the first hypothesis that certainly reaches `need` (count >= need + margin) is ever looked at
+        by the reference (`break`, ransac.py:186-190);
+      * inside that prefix: every flagged hypothesis (its reference H is LAPACK's arbitrary null vector), every one
+        within `margin` of `need`, and every one within `margin` of the running maximum.
+    Returns (winner | None, early, count, mask_words | None, H_rows, counts): mask_words is the winner's uint64 mask
+    if the winner was settled here (None: take K2's own mask for it), H_rows maps settled index -> float32[9], counts
+    is the int64 count table with the settled entries replaced."""
+    import torch
+    k = counts.shape[0]
+    counts = counts.astype(np.int64)
+    settled = np.zeros(k, dtype=bool)
+    suspect = flags != 0
+    masks = {}
+    rows = {}
+    n_rounds = 0
+    while True:
+        # the reference never runs past the first hypothesis that reaches `need` (certainly: settled, or by a margin)
+        hit = np.flatnonzero(np.where(settled, counts >= need, counts >= need + margin))
+        end = int(hit[0]) + 1 if hit.size else k
+        c = counts[:end]
+        best = int(c.max()) if end else 0
+        cand = np.flatnonzero(~settled[:end] & suspect[:end])
+        if cand.size == 0:   # flagged samples first: their true counts can move the best the margin is measured from
+            cand = np.flatnonzero(~settled[:end] & ((c >= best - margin) | (c >= need - margin)))
+        if cand.size == 0:
+            break
+        n_rounds += 1
+        H = svd_hypotheses(pa, pb, idx_host[cand])
+        hd = torch.from_numpy(H).to(pa_dev.device)
+        cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.new_best(pa_dev.device))
+        msk = msk.cpu().numpy()
+        counts[cand] = cnt.cpu().numpy()
+        settled[cand] = True
+        for j, i in enumerate(cand.tolist()):
+            masks[i] = msk[j]
+            rows[i] = H[j]
+    if stats is not None:
+        stats["host_settled"] = int(settled.sum())
+        stats["host_rounds"] = n_rounds
+    hit = np.flatnonzero(c >= need)
+    if hit.size:
+        w, early = int(hit[0]), True
+    elif end and c.max() > 0:
+        w, early = int(np.argmax(c)), False               # first index of the maximum (ransac.py:199: strict >)
+    else:
+        return None, False, 0, None, rows, counts
+    return w, early, int(c[w]), masks.get(w), rows, counts
 
 
 class Model(object):
@@ -126,7 +211,7 @@ class HomoModel(Model):
 class RANSAC(object):
     """ransac.py:137-213."""
 
-    __slots__ = ('model', 'th', 'd', 'n', 'k', 'last_run')
+    __slots__ = ('model', 'th', 'd', 'n', 'k', 'last_run', 'rescore_margin')
 
     def __init__(self, model, k=1000):
         self.model = model
@@ -135,6 +220,7 @@ class RANSAC(object):
         self.n = model.n
         self.k = k
         self.last_run = None
+        self.rescore_margin = RESCORE_MARGIN
 
     def computeLoss(self, X, Y, method="reproj"):
         return self.model.computeLoss(X, Y, method)
@@ -160,34 +246,38 @@ class RANSAC(object):
         rng_state = np.random.get_state()
         idx_host = np.random.randint(0, mx, (k, self.n))
 
-        pa = torch.from_numpy(_points_rows(X)).to(dev)
-        pb = torch.from_numpy(_points_rows(Y)).to(dev)
+        pa_host, pb_host = _points_rows(X), _points_rows(Y)
+        pa = torch.from_numpy(pa_host).to(dev)
+        pb = torch.from_numpy(pb_host).to(dev)
         idx = torch.from_numpy(idx_host.astype(np.int32)).to(dev)
         ws = kernels.SearchWorkspace(k, mx, dev)
-        kernels.ransac_search(pa, pb, idx, _weak_threshold(self.th), method, kernels.need_count(mx, self.d, self.n), ws)
+        need_i = kernels.need_count(mx, self.d, self.n)
+        th = _weak_threshold(self.th)
+        kernels.ransac_search(pa, pb, idx, th, method, need_i, ws)
         Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
-        winner, _, early = kernels.decode_best(ws.best.cpu().numpy(), k)
+        counts_host = counts.cpu().numpy()
+        stats = {}
+        winner, early, totalfit, mask_words, settled_rows, counts_host = _settle_on_host(
+            pa, pb, pa_host, pb_host, idx_host, counts_host, flags.cpu().numpy(), need_i, th, method,
+            self.rescore_margin, stats)
 
-        last_iter = winner if early else k - 1
         if early:  # leave the generator where the reference's `break` would
             np.random.set_state(rng_state)
             np.random.randint(0, mx, (winner + 1, self.n))
-        tail = counts[[last_iter] + ([winner] if winner is not None else [])].cpu().numpy()
-        if tail[0] < need:  # ransac.py:203-204 (uses the LAST iteration's count in the test)
-            best_cnt = int(tail[1]) if winner is not None else 0
-            print("Warning:: fitting model does not exceed required threshold %d vs %d" % (best_cnt, need))
+        elif k and counts_host[k - 1] < need:  # ransac.py:203-204 tests the LAST iteration's count
+            print("Warning:: fitting model does not exceed required threshold %d vs %d" % (totalfit, need))
 
-        if winner is None or int(tail[1]) == 0:
+        if winner is None:
             # ransac.py:206-208 with inliers_pos_final = None: np.where(None) -> empty -> fit asserts
             inliers = (np.array([], dtype=np.int64),)
             totalfit = 0
         else:
-            words = masks[winner].cpu().numpy().view(np.uint64)
-            bits = np.unpackbits(words.view(np.uint8), bitorder="little")[:mx]
+            words = mask_words if mask_words is not None else masks[winner].cpu().numpy()
+            bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:mx]
             inliers = (np.nonzero(bits)[0].astype(np.int64),)
-            totalfit = np.int64(tail[1])
+            totalfit = np.int64(totalfit)
         self.last_run = {"winner": winner, "early_exit": early, "counts": counts, "flags": flags,
-                         "hypotheses": Hs, "idx": idx_host}
+                         "hypotheses": Hs, "idx": idx_host, "settled": settled_rows, **stats}
         inliers_x = X[:, inliers[0]]
         inliers_y = Y[:, inliers[0]]
         DEBUG("Fitting final model using all inliers")
@@ -229,7 +319,8 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     offsets[1:] = np.cumsum(sizes)
     pa = torch.from_numpy(np.concatenate([_points_rows(X) for X, _ in datas])).to(dev)
     pb = torch.from_numpy(np.concatenate([_points_rows(Y) for _, Y in datas])).to(dev)
-    needs = torch.tensor([kernels.need_count(m, d, n) for m in sizes], dtype=torch.int32, device=dev)
+    needs_host = [kernels.need_count(m, d, n) for m in sizes]
+    needs = torch.tensor(needs_host, dtype=torch.int32, device=dev)
     ws = kernels.BatchWorkspace(P, int(k), max(max(sizes), 1), dev)
     if idx is not None:
         table = torch.from_numpy(np.stack([np.asarray(t).astype(np.int32) for t in idx])).to(dev)
@@ -237,18 +328,35 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     else:
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed,
                                problem_base=problem_base)
-    best = ws.best.cpu().numpy()
-    winners = [kernels.decode_best(best[p], int(k)) for p in range(P)]
+    if idx is not None:
+        # the caller's tables may hold repeated indices (numpy's sampler draws with replacement): settle every problem
+        # with the reference's solver, exactly as RANSAC.run does
+        counts_host = ws.counts.cpu().numpy()
+        flags_host = ws.flags.cpu().numpy()
+        pa_host, pb_host = pa.cpu().numpy(), pb.cpu().numpy()
+        winners, win_counts, host_masks = [], [], []
+        for p in range(P):
+            o0, o1 = int(offsets[p]), int(offsets[p + 1])
+            w, early, cnt, words, _, _ = _settle_on_host(pa[o0:o1], pb[o0:o1], pa_host[o0:o1], pb_host[o0:o1], np.asarray(idx[p]),
+                                                     counts_host[p], flags_host[p], needs_host[p], _weak_threshold(th),
+                                                     method, RESCORE_MARGIN)
+            winners.append((w, None, early)); win_counts.append(cnt); host_masks.append(words)
+    else:
+        best = ws.best.cpu().numpy()
+        winners = [kernels.decode_best(best[p], int(k)) for p in range(P)]
+        host_masks = [None] * P
     rows = torch.tensor([[p, w[0] if w[0] is not None else 0] for p, w in enumerate(winners)], device=dev)
     win_masks = ws.masks[rows[:, 0], rows[:, 1]].cpu().numpy()          # one gather, one copy for all problems
-    win_counts = ws.counts[rows[:, 0], rows[:, 1]].cpu().numpy()
+    if idx is None:
+        win_counts = ws.counts[rows[:, 0], rows[:, 1]].cpu().numpy()
     out = []
     for p, ((X, Y), (winner, _, early)) in enumerate(zip(datas, winners)):
         model = HomoModel(th=th, d=d, n=n)
         if winner is None or int(win_counts[p]) == 0:
             inliers, total = (np.array([], dtype=np.int64),), 0
         else:
-            bits = np.unpackbits(win_masks[p].view(np.uint8), bitorder="little")[:sizes[p]]
+            words = host_masks[p] if host_masks[p] is not None else win_masks[p]
+            bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:sizes[p]]
             inliers, total = (np.nonzero(bits)[0].astype(np.int64),), np.int64(win_counts[p])
         try:
             H = model.fit(X[:, inliers[0]], Y[:, inliers[0]], collective=True)

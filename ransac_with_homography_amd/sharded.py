@@ -29,15 +29,28 @@ def _dist():
 
 
 def gpu_score_slice(pa, pb, idx_slice, th, loss, need, hyp_base):
-    """Product backend: K1 + K2 on this rank's GPU.  Returns the 2 x int64 key tensor (on the GPU)."""
+    """Product backend: K1 + K2 on this rank's GPU over its slice of the index table, then the slice's accept rules with
+    the reference's solver on every hypothesis that can decide them (`ransac._settle_on_host`: samples with a repeated
+    index, counts within a margin of the slice's best / of `need`).  A hypothesis within the margin of the GLOBAL best
+    is within the margin of its own slice's best, so settling needs no exchange and the path keeps its ONE collective.
+    Returns the slice's two packed keys (include/rwh.h, rwh_score_count) as a 2 x int64 tensor on the GPU."""
     import torch
     from . import kernels
-    best = kernels.new_best(pa.device)
-    if idx_slice.shape[0]:
-        idx = torch.from_numpy(np.ascontiguousarray(idx_slice, dtype=np.int32)).to(pa.device)
-        Hs, _ = kernels.dlt4_batched(pa, pb, idx)
-        kernels.score_count(Hs, pa, pb, th, loss, need, best, hyp_base=hyp_base, want_masks=False)
-    return best
+    from .ransac import RESCORE_MARGIN, _settle_on_host
+    k = idx_slice.shape[0]
+    w0 = w1 = 0
+    if k:
+        idx_host = np.ascontiguousarray(idx_slice, dtype=np.int32)
+        ws = kernels.SearchWorkspace(k, pa.shape[0], pa.device, want_masks=False)
+        kernels.ransac_search(pa, pb, torch.from_numpy(idx_host).to(pa.device), th, loss, need, ws, hyp_base=hyp_base)
+        winner, early, count, _, _, _ = _settle_on_host(pa, pb, pa.cpu().numpy(), pb.cpu().numpy(), idx_host,
+                                                        ws.counts.cpu().numpy(), ws.flags.cpu().numpy(), need, th, loss,
+                                                        RESCORE_MARGIN)
+        if winner is not None:
+            inv = 0xFFFFFFFF - (hyp_base + winner)
+            w0 = (int(count) << 32) | inv
+            w1 = inv if early else 0
+    return torch.tensor([w0, w1], dtype=torch.int64, device=pa.device)
 
 
 def ransac_sharded(pa, pb, idx_table, th, loss, need, score_slice=gpu_score_slice, group=None):
@@ -60,12 +73,14 @@ def ransac_sharded(pa, pb, idx_table, th, loss, need, score_slice=gpu_score_slic
 
 
 def winner_inliers(pa, pb, idx_row, th, loss):
-    """Inlier indices of one hypothesis, recomputed locally by every rank (deterministic)."""
+    """Inlier indices of one hypothesis, recomputed locally by every rank (deterministic): H by the reference's own
+    solver on the host (`ransac.svd_hypotheses`, one 8 x 9 SVD), scored by K2."""
     import torch
     from . import kernels
-    idx = torch.from_numpy(np.ascontiguousarray(idx_row, dtype=np.int32).reshape(1, 4)).to(pa.device)
-    Hs, _ = kernels.dlt4_batched(pa, pb, idx)
-    counts, masks, _ = kernels.score_count(Hs, pa, pb, th, loss, 1 << 30, kernels.new_best(pa.device))
+    from .ransac import svd_hypotheses
+    H = svd_hypotheses(pa.cpu().numpy(), pb.cpu().numpy(), np.asarray(idx_row).reshape(1, 4))
+    counts, masks, _ = kernels.score_count(torch.from_numpy(H).to(pa.device), pa, pb, th, loss, 1 << 30,
+                                           kernels.new_best(pa.device))
     bits = np.unpackbits(masks[0].cpu().numpy().view(np.uint8), bitorder="little")[:pa.shape[0]]
     return np.nonzero(bits)[0].astype(np.int64), int(counts[0])
 

@@ -146,6 +146,89 @@ def g4_g5(ptsA, ptsB):
     save("g4_ransac_runs", **out)
 
 
+def contaminate(ptsB, seed, fracs):
+    """Replace a random subset of the matches' second points by uniform noise (the last fraction decides)."""
+    rng = np.random.default_rng(seed)
+    for frac in fracs:
+        Bc = ptsB.copy()
+        m = rng.random(ptsB.shape[0]) < frac
+        Bc[m] = rng.uniform(0, 1000, (int(m.sum()), 2)).astype(np.float32)
+    return Bc
+
+
+def g9(ptsA, ptsB):
+    """Low-inlier problems on which the REFERENCE's winner is a sample with a repeated index: np.random.randint draws
+    with replacement (ransac.py:177), the rank-deficient 8x9 system still yields an H (LAPACK's arbitrary null vector,
+    homography.py:81-87) and that H competes for the best (ransac.py:199-202).  Per case: the run's outputs and the
+    reference's per-iteration H / counts (model.fit + computeLoss, exactly the loop body)."""
+    out = {}
+    names = []
+    cases = [("a", 0, (0.0, 0.3, 0.5), 2, 5, 70, 1000, "fwd"),
+             ("a", 0, (0.0, 0.3, 0.5), 2, 5, 70, 1000, "backward"),
+             ("a", 0, (0.0, 0.3, 0.5), 2, 5, 70, 1000, "reproj"),
+             ("a", 0, (0.0, 0.3, 0.5), 2, 5, 20, 1000, "fwd"),      # need = 41: the repeated sample 151 triggers `break`
+             ("b", 9, (0.7,), 2, 5, 70, 1000, "fwd"),
+             ("c", 11, (0.6,), 0, 5, 70, 1000, "fwd")]
+    for tag, cseed, fracs, seed, th, d, k, m in cases:
+        Bc = contaminate(ptsB, cseed, fracs)
+        out["ptsB_" + tag] = Bc
+        H, inl, cnt = run_ref_ransac(ptsA, Bc, seed, th, d, k, m)
+        key = "%s_s%d_th%d_d%d_k%d_%s" % (tag, seed, th, d, k, m)
+        names.append(key)
+        X, Y = ptsA.T, Bc.T
+        np.random.seed(seed)
+        idx = np.random.randint(0, X.shape[1], (k, 4))
+        model = ref_r.HomoModel(th=th, d=d, n=4)
+        Hs = np.empty((k, 9), np.float32)
+        counts = np.empty(k, np.int32)
+        with np.errstate(all="ignore"):
+            for i in range(k):
+                Hs[i] = model.fit(X[:, idx[i]], Y[:, idx[i]]).reshape(9)
+                counts[i] = np.sum(model.computeLoss(X, Y, m) < th)
+        need = X.shape[1] * d / 100 + 4
+        hit = np.nonzero(counts >= need)[0]
+        win = int(hit[0]) if hit.size else int(np.argmax(counts))
+        assert counts[win] == cnt, (key, counts[win], cnt)
+        out[key + "_H"] = H
+        out[key + "_inliers"] = inl
+        out[key + "_count"] = cnt
+        out[key + "_idx"] = idx.astype(np.int32)
+        out[key + "_hyp_H"] = Hs
+        out[key + "_hyp_counts"] = counts
+        out[key + "_winner"] = np.int64(win)
+        out[key + "_early"] = np.bool_(hit.size > 0)
+        print(key, "count", int(cnt), "winner", win, idx[win].tolist(), "early" if hit.size else "")
+    out["cases"] = np.array(names)
+    save("g9_low_inlier", **out)
+
+
+def g10(ptsA, ptsB):
+    """BASELINE config 5's search: 100 000 hypotheses (seed 0) on matchespoints, th = 5, 'fwd' -- the reference's loop
+    body per hypothesis.  Winner / count / inlier list, and the counts themselves (int16) + their SHA-256."""
+    X, Y = ptsA.T, ptsB.T
+    K = 100000
+    np.random.seed(0)
+    idx = np.random.randint(0, X.shape[1], (K, 4))
+    model = ref_r.HomoModel(th=5, d=70, n=4)
+    counts = np.empty(K, np.int32)
+    win_mask = None
+    best = 0
+    with np.errstate(all="ignore"):
+        for i in range(K):
+            model.fit(X[:, idx[i]], Y[:, idx[i]])
+            inl = model.computeLoss(X, Y, "fwd") < 5
+            counts[i] = np.sum(inl)
+            if counts[i] > best:
+                best, win_mask = counts[i], inl
+    win = int(np.argmax(counts))
+    save("g10_config5_search", K=np.int64(K), seed=np.int64(0), counts=counts.astype(np.int16),
+         counts_sha256=np.array(sha(counts)), winner=np.int64(win), winner_count=np.int64(counts[win]),
+         winner_ties=np.int64(np.sum(counts == counts[win])), winner_sample=idx[win].astype(np.int32),
+         winner_inliers=np.where(win_mask)[0].astype(np.int64),
+         degenerate=np.int64(sum(len(set(r)) < 4 for r in idx.tolist())))
+    print("g10 winner", win, int(counts[win]))
+
+
 def small_images():
     rng = np.random.default_rng(1234)
     noise = rng.integers(0, 256, (48, 64, 3), dtype=np.uint8)
@@ -241,7 +324,7 @@ def g8():
 
 
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -250,6 +333,8 @@ def main():
     if "g6" in which: g6()
     if "g7" in which: g7()
     if "g8" in which: g8()
+    if "g9" in which: g9(ptsA, ptsB)
+    if "g10" in which: g10(ptsA, ptsB)
 
 
 if __name__ == "__main__":

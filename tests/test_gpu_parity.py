@@ -42,6 +42,18 @@ def gpu():
     return _lib.require_gpu()  # raises (test error, not skip) when the HIP path is unavailable
 
 
+def _force_shape(shape):
+    """Pin (or release, None) the fast bilinear kernel's patch shape through the lab hook of the C ABI."""
+    from ransac_with_homography_amd import _lib
+    assert _lib.load().rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, int(shape) if shape else 0) == 0
+
+
+@pytest.fixture(autouse=True)
+def release_lab_overrides():
+    yield
+    _force_shape(None)
+
+
 def close(gpu_img, ref):
     ref = ref.astype(np.float64)
     return np.abs(gpu_img.astype(np.float64) - ref) <= 1e-4 * np.abs(ref) + 1e-5
@@ -333,6 +345,127 @@ def test_ransac_run_matches_reference_runs(gpu, matches):
         assert nxt == np.random.randint(0, 1 << 30), key
 
 
+def test_ransac_run_low_inlier_reference_winner(gpu, matches):
+    """G9: contaminated problems on which the REFERENCE's winner is a sample with a repeated index (np.random.randint
+    draws with replacement, LAPACK still returns a null vector, that H wins: ransac.py:177,199-202, homography.py:81-87).
+    RANSAC.run must return the reference's iteration, count and inlier list -- including the case where the repeated
+    sample triggers the early `break` -- and run_batch(idx=) the same."""
+    import ransac as rs
+    from ransac_with_homography_amd import ransac as rmod
+    z = load_golden("g9_low_inlier")
+    ptsA, _ = matches
+    for key in [str(k) for k in z["cases"]]:
+        tag, s, th, d, k, method = key.split("_")
+        B = z["ptsB_" + tag]
+        np.random.seed(int(s[1:]))
+        model = rs.HomoModel(th=int(th[2:]), d=int(d[1:]), n=4)
+        r = rs.RANSAC(model, k=int(k[1:]))
+        H, inl, cnt = r.run([ptsA.T, B.T], method=method)
+        w = r.last_run["winner"]
+        assert w == int(z[key + "_winner"]) and len(set(z[key + "_idx"][w].tolist())) < 4, key
+        assert int(cnt) == int(z[key + "_count"]) and np.array_equal(inl[0], z[key + "_inliers"]), key
+        assert r.last_run["early_exit"] == bool(z[key + "_early"])
+        np.testing.assert_allclose(H, z[key + "_H"], rtol=1e-3, atol=1e-6, err_msg=key)
+        assert np.array_equal(r.last_run["settled"][w].view(np.uint32), z[key + "_hyp_H"][w].view(np.uint32))
+        print(key, "host-settled hypotheses:", r.last_run["host_settled"], "in", r.last_run["host_rounds"], "rounds")
+        assert 30 <= r.last_run["host_settled"] <= 250, r.last_run["host_settled"]   # ~3.7 % repeated + the near-best
+        # generator left where the reference's loop leaves it
+        nxt = np.random.randint(0, 1 << 30)
+        np.random.seed(int(s[1:]))
+        np.random.randint(0, 185, ((w + 1) if bool(z[key + "_early"]) else int(k[1:]), 4))
+        assert nxt == np.random.randint(0, 1 << 30), key
+        got = rmod.run_batch([[ptsA.T, B.T]], th=int(th[2:]), d=int(d[1:]), k=int(k[1:]), method=method, idx=[z[key + "_idx"]])
+        assert int(got[0][2]) == int(cnt) and np.array_equal(got[0][1][0], inl[0]) and np.array_equal(got[0][0], H), key
+
+
+def test_config5_search_100k_hypotheses(gpu, matches):
+    """BASELINE config 5's search (G10: the reference's loop body over 100 000 samples, seed 0): the single search and a
+    2-shard split of the hypothesis range (sharded.gpu_score_slice with hyp_base, keys merged by MAX as the all-reduce
+    does) both return the reference's winner, count and inlier list; K1 + K2's raw counts differ from the reference's
+    only on flagged samples and, by at most 2, on a handful of ill-conditioned ones (what RESCORE_MARGIN covers)."""
+    import ransac as rs
+    from ransac_with_homography_amd import kernels, sharded
+    from ransac_with_homography_amd import ransac as rmod
+    z = load_golden("g10_config5_search")
+    ptsA, ptsB = matches
+    K = int(z["K"])
+    np.random.seed(0)
+    r = rs.RANSAC(rs.HomoModel(th=5, d=70, n=4), k=K)
+    H, inl, cnt = r.run([ptsA.T, ptsB.T], method="fwd")
+    assert (r.last_run["winner"], int(cnt)) == (int(z["winner"]), int(z["winner_count"])) == (99206, 122)
+    assert np.array_equal(inl[0], z["winner_inliers"]) and np.array_equal(r.last_run["idx"][99206], z["winner_sample"])
+    raw = r.last_run["counts"].cpu().numpy().astype(np.int64)
+    flagged = r.last_run["flags"].cpu().numpy() != 0
+    assert int(flagged.sum()) == int(z["degenerate"])
+    ref = z["counts"].astype(np.int64)
+    diff = np.abs(raw - ref)[~flagged]
+    print("config 5: raw count mismatches on unflagged samples:", int((diff != 0).sum()), "max", int(diff.max()),
+          "host-settled:", r.last_run["host_settled"])
+    assert diff.max() <= 3 < rmod.RESCORE_MARGIN and (diff != 0).mean() < 1e-3
+    # 2 shards
+    pa, pb = torch.from_numpy(ptsA).to(gpu), torch.from_numpy(ptsB).to(gpu)
+    idx = r.last_run["idx"]
+    keys = [sharded.gpu_score_slice(pa, pb, idx[b:e], 5.0, "fwd", kernels.need_count(185, 70, 4), b)
+            for b, e in (sharded.shard_range(K, 0, 2), sharded.shard_range(K, 1, 2))]
+    merged = torch.maximum(keys[0], keys[1]).cpu().numpy()
+    assert kernels.decode_best(merged, K) == (99206, 122, False)
+    inl2, c2 = sharded.winner_inliers(pa, pb, idx[99206], 5.0, "fwd")
+    assert c2 == 122 and np.array_equal(inl2, z["winner_inliers"])
+
+
+def test_batched_short_tables_exact_size_buffers(gpu, matches):
+    """rwh_ransac_batched with k < 64 and P*k not a multiple of 64 (P = 3, k = 10) on buffers of EXACTLY the required
+    size (hipMalloc through ctypes, no allocator slack): lanes past the last hypothesis must not index the offsets table
+    or the points (they used to read offsets[t / k] for t >= P*k)."""
+    import ctypes
+    from ransac_with_homography_amd import _lib, kernels
+    lib = _lib.load()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_size_t]
+    hip.hipFree.argtypes = [ctypes.c_void_p]
+    hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    ptsA, ptsB = matches
+    sizes, P, K = [185, 40, 7], 3, 10
+    A = np.concatenate([ptsA[:m] for m in sizes]).astype(np.float32)
+    B = np.concatenate([ptsB[:m] for m in sizes]).astype(np.float32)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    rng = np.random.default_rng(5)
+    idx = np.stack([rng.integers(0, m, (K, 4)) for m in sizes]).astype(np.int32)
+    needs = np.array([kernels.need_count(m, 70, 4) for m in sizes], np.int32)
+    words = 3
+    bufs = {}
+
+    def dev(name, nbytes, host=None):
+        ptr = ctypes.c_void_p()
+        assert hip.hipMalloc(ctypes.byref(ptr), nbytes) == 0
+        if host is not None:
+            assert hip.hipMemcpy(ptr, host.ctypes.data_as(ctypes.c_void_p), nbytes, 1) == 0
+        bufs[name] = (ptr, nbytes)
+        return ptr
+
+    try:
+        d_a, d_b = dev("a", A.nbytes, A), dev("b", B.nbytes, B)
+        d_off, d_idx, d_need = dev("off", offs.nbytes, offs), dev("idx", idx.nbytes, idx), dev("need", needs.nbytes, needs)
+        d_h, d_fl, d_cnt = dev("h", P * K * 36), dev("fl", P * K), dev("cnt", P * K * 4)
+        d_mask, d_best = dev("mask", P * K * words * 8), dev("best", P * 16)
+        torch.cuda.synchronize()
+        st = lib.rwh_ransac_batched(d_a, d_b, d_off, P, 185, K, d_idx, 0, 0, 5.0, 0, d_need, d_h, d_fl, d_cnt, d_mask, d_best, 0, None)
+        assert st == 0
+        torch.cuda.synchronize()
+        Hout = np.empty((P, K, 9), np.float32); cnt = np.empty((P, K), np.int32)
+        assert hip.hipMemcpy(Hout.ctypes.data_as(ctypes.c_void_p), d_h, Hout.nbytes, 2) == 0
+        assert hip.hipMemcpy(cnt.ctypes.data_as(ctypes.c_void_p), d_cnt, cnt.nbytes, 2) == 0
+    finally:
+        for ptr, _ in bufs.values():
+            hip.hipFree(ptr)
+    for p, m in enumerate(sizes):     # every problem equals its own single search on torch buffers
+        pa, pb = torch.from_numpy(A[offs[p]:offs[p] + m]).to(gpu), torch.from_numpy(B[offs[p]:offs[p] + m]).to(gpu)
+        ws = kernels.SearchWorkspace(K, m, gpu)
+        kernels.ransac_search(pa, pb, torch.from_numpy(idx[p]).to(gpu), 5.0, "fwd", int(needs[p]), ws)
+        assert np.array_equal(ws.H.cpu().numpy().view(np.uint32), Hout[p].view(np.uint32)), p
+        assert np.array_equal(ws.counts.cpu().numpy(), cnt[p]), p
+
+
 def _batch_problems(matches):
     """Five problems of different sizes cut from the 185 real correspondences (3 mask words down to 1; one with
     exactly 4 points)."""
@@ -563,17 +696,57 @@ def test_config4_panorama_8k_end_to_end(gpu, matches):
     assert out.dtype == np.uint8 and out.shape[2] == 3
     # the query image is pasted unchanged; the warped part is non-trivial
     assert out[:, : B8.shape[1]].any() and out[:, B8.shape[1]:].any()
+    # pixels: oracle-computed 256 x 256 canvas windows (the reference's float64 arithmetic on exactly those output
+    # coordinates, homography.py:166-179 + 335-338 / 322-334), bit for bit: one straddling the seam at the right edge of
+    # the pasted query image, one straddling the top edge of the warped image, one deep inside the warped part
+    from oracle import rwh_oracle as orc
+    h8, w8, _ = A8.shape
+    mx, my, wt, ht = orc.output_bounds(h8, w8, H8, 0)
+    (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (fw, fh) = orc.stitch_geometry(wt, ht, B8.shape[1], B8.shape[0], mx, my)
+    assert out.shape == (fh, fw, 3)
+    inv8 = np.linalg.inv(H8)
+    blended = hg.stitchPanorama(B8, A8, H8, blending="Rate", blendrate=0.2)
+    for (cx, cy) in ((qex - 128, (qsy + qey) // 2), ((tsx + tex) // 2, max(tsy, qsy) - 100 if max(tsy, qsy) > 100 else tsy),
+                     (tex - 1500, (tsy + tey) // 2)):
+        x0, y0 = max(cx, 0), max(cy, 0)
+        xs, ys = np.arange(x0, x0 + 256), np.arange(y0, y0 + 256)
+        in_t = ((xs >= tsx) & (xs <= tex))[None, :] & ((ys >= tsy) & (ys <= tey))[:, None]
+        in_q = ((xs >= qsx) & (xs <= qex))[None, :] & ((ys >= qsy) & (ys <= qey))[:, None]
+        warped = _oracle_warp_on_grid(A8, inv8, (xs - tsx + mx).astype(np.float64), (ys - tsy + my).astype(np.float64), (h8, w8))
+        qwin = np.zeros((256, 256, 3), np.uint8)
+        yy, xx = np.nonzero(in_q)
+        qwin[yy, xx] = B8[ys[yy] - qsy, xs[xx] - qsx]
+        # paste (homography.py:335-338)
+        ref = np.zeros((256, 256, 3), np.uint8)
+        ref[in_t] = warped.astype(np.uint8)[in_t]
+        ref[in_q] = qwin[in_q]
+        assert np.array_equal(out[y0:y0 + 256, x0:x0 + 256], ref), (cx, cy)
+        # 'Rate' blend (homography.py:322-334): float32 canvas RGBA, alpha-weighted average on the warped rectangle
+        rate = np.float32(0.2 + 1e-10)
+        can = np.zeros((256, 256, 4), np.float32)
+        can[:, :, :3][in_q] = qwin[in_q].astype(np.float32)
+        can[:, :, 3] += 1e-10
+        can[:, :, 3][in_q] = 1 + 1e-10 - 0.2
+        rgba = np.concatenate([A8, np.zeros((h8, w8, 1), np.uint8)], axis=2).astype(np.float32)
+        rgba[:, :, 3] = rate
+        wt4 = _oracle_warp_on_grid(rgba, inv8, (xs - tsx + mx).astype(np.float64), (ys - tsy + my).astype(np.float64), (h8, w8))
+        base = can[:, :, 3:4] + wt4[:, :, 3:4]
+        mixed = (can[:, :, 3:4] / base) * can[:, :, :3] + (wt4[:, :, 3:4] / base) * wt4[:, :, :3]
+        refb = can[:, :, :3].copy()
+        refb[in_t] = mixed[in_t]
+        assert np.array_equal(blended[y0:y0 + 256, x0:x0 + 256], refb.astype(np.uint8)), ("rate", cx, cy)
+        del rgba
 
 
 def test_config5_batch_1080p(gpu):
-    """BASELINE config 5 (per-GPU share): a batch of 1080p frames in ONE launch equals frame-by-frame launches."""
+    """BASELINE config 5 (per-GPU share, 64 of the 512 frames): the batch in ONE launch equals frame-by-frame launches."""
     from ransac_with_homography_amd import kernels
     g = torch.Generator(device="cpu").manual_seed(7)
-    src = torch.randint(0, 256, (8, 1080, 1920, 3), dtype=torch.uint8, generator=g).to(gpu)
+    src = torch.randint(0, 256, (64, 1080, 1920, 3), dtype=torch.uint8, generator=g).to(gpu)   # one GPU's 64 of the 512
     inv = np.linalg.inv(H_BENCH)
     grid = kernels.Grid(0, 1919, 1920, 0, 1079, 1080)
     full = kernels.warp_backward(src, inv, grid, (1080, 1920), "bilinear", torch.uint8)
-    for b in (0, 3, 7):
+    for b in (0, 3, 31, 63):
         assert torch.equal(kernels.warp_backward(src[b].contiguous(), inv, grid, (1080, 1920), "bilinear", torch.uint8), full[b])
     # nearest-neighbour batch path too
     nn = kernels.warp_backward(src, inv, grid, (1080, 1920), "nn", torch.uint8)
@@ -632,14 +805,11 @@ def test_warp_fallback_paths_vs_oracle(gpu, case):
 @pytest.mark.parametrize("shape", ["7", "6", "5", None])
 @pytest.mark.parametrize("case", ["mild", "rot4", "rot12", "rot45", "rot89", "persp"])
 def test_warp_patch_shapes_vs_oracle(gpu, case, shape, monkeypatch):
-    """The 8 px kernel's three patch shapes (128x4 / 64x8 / 32x16, RWH_WARP_SHAPE forces one, None = the host's
+    """The 8 px kernel's three patch shapes (128x4 / 64x8 / 32x16, rwh_lab_tune forces one, None = the host's
     choice) against the oracle on rotations that fit some shapes' slabs and not others, on a grid wider than one
     tile with a ragged right edge and bottom (tile shift / row clamp)."""
     from ransac_with_homography_amd import kernels
-    if shape is None:
-        monkeypatch.delenv("RWH_WARP_SHAPE", raising=False)
-    else:
-        monkeypatch.setenv("RWH_WARP_SHAPE", shape)
+    _force_shape(shape)
     rng = np.random.default_rng(5)
     img = rng.integers(0, 256, (333, 517, 3), dtype=np.uint8)
 
@@ -701,10 +871,7 @@ def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
         grid = kernels.Grid(xs[0], xs[-1], ow, ys[0], ys[-1], oh)
         xs, ys = np.linspace(xs[0], xs[-1], ow), np.linspace(ys[0], ys[-1], oh)
         shape = [None, "5", "6", "7"][int(rng.integers(0, 4))]
-        if shape is None:
-            monkeypatch.delenv("RWH_WARP_SHAPE", raising=False)
-        else:
-            monkeypatch.setenv("RWH_WARP_SHAPE", shape)
+        _force_shape(shape)
         ref = _oracle_warp_on_grid(img, inv, xs, ys, (sh, sw))
         src = torch.from_numpy(img).to(gpu)
         got = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.float32).cpu().numpy()
@@ -745,10 +912,7 @@ def test_nearest_fast_kernel_bit_exact(gpu, case, exact, monkeypatch):
     ref = _oracle_nn_on_grid(img, inv, xs, ys, (301, 433))
     src = torch.from_numpy(img).to(gpu)
     for shape in ("5", "6", "7", None):
-        if shape is None:
-            monkeypatch.delenv("RWH_WARP_SHAPE", raising=False)
-        else:
-            monkeypatch.setenv("RWH_WARP_SHAPE", shape)
+        _force_shape(shape)
         got = kernels.warp_backward(src, inv, grid, (301, 433), "nn", torch.uint8, exact=exact).cpu().numpy()
         bad = int((got != ref).any(axis=2).sum())
         assert bad == 0, (case, shape, exact, bad)

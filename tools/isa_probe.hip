@@ -1,0 +1,269 @@
+// Developer microbenchmark (NOT part of the product): round-2 questions about gfx950 instructions the bilinear
+// warp kernel could be rebuilt from.  Rates are reported relative to v_fma_f32 measured in the same run.
+//   hipcc -O3 --offload-arch=gfx950 tools/isa_probe.hip -o tools/isa_probe && gpurun -- ./tools/isa_probe
+//
+//  1. semantics: v_fma_mix_f32 / v_dot2_f32_f16 on f16 DENORMAL inputs (a byte b zero-extended to 16 bits is the
+//     f16 denormal b * 2^-24: no byte->float convert needed if the mix unit honours it), v_mul_f32_sdwa on a byte
+//     select (the f32 denormal b * 2^-149), unaligned ds_read_b64, global_load_lds_dwordx4 placement;
+//  2. VALU issue cost of those instructions;
+//  3. LDS read issue cost per CU: ds_read_b32 / read2_b32 / b64 / read2_b64 / b128, aligned and byte-misaligned,
+//     at the strides a tap fetch produces.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cstdint>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+
+constexpr int ITERS = 512;
+
+// ---------------------------------------------------------------- semantics ----
+__global__ void k_semantics(float* out, const uint32_t* in) {
+    const uint32_t pix = in[0];          // bytes 0x11 0x7f 0xff 0x03 -> 17, 127, 255, 3
+    const float scale24 = 16777216.0f;   // 2^24
+    uint32_t lohi = pix & 0x00ff00ffu;   // f16 lanes: byte0, byte2
+    float r0, r1, r2, r3, r4, r5;
+    const float zero = 0.f;
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(lohi), "v"(scale24), "v"(zero));               // lo half
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(lohi), "v"(scale24), "v"(zero)); // hi half
+    // dot2: (b0, b2) . (w0, w1) with f16 weights 1.0 and 2.0, times 2^24 afterwards
+    const uint32_t w = 0x40003c00u;      // f16 {1.0, 2.0}
+    asm volatile("v_dot2_f32_f16 %0, %1, %2, %3" : "=v"(r2) : "v"(lohi), "v"(w), "v"(zero));
+    r2 *= scale24;
+    // sdwa: byte 1 of pix as an f32 denormal (b * 2^-149) times 2^126, then * 2^23
+    const float big = 8.507059e37f;      // 2^126
+    asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r3) : "v"(pix), "v"(big));
+    r3 *= 8388608.0f;
+    asm volatile("v_cvt_f32_ubyte3 %0, %1" : "=v"(r4) : "v"(pix));
+    // packed mul
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a = {3.f, 5.f}, b = {7.f, 11.f}, c;
+    asm volatile("v_pk_mul_f32 %0, %1, %2" : "=v"(c) : "v"(a), "v"(b));
+    r5 = c.x + c.y;
+    if (threadIdx.x == 0) { out[0] = r0; out[1] = r1; out[2] = r2; out[3] = r3; out[4] = r4; out[5] = r5; }
+
+    // unaligned LDS reads
+    __shared__ unsigned char lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += blockDim.x) lds[i] = (unsigned char)(i * 7 + 1);
+    __syncthreads();
+    const unsigned addr = (unsigned)(uintptr_t)lds + 3 + 8 * threadIdx.x + (threadIdx.x & 3);   // byte-misaligned
+    uint2 v;
+    asm volatile("ds_read_b64 %0, %1\n s_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(addr));
+    uint32_t want0 = 0, want1 = 0;
+    const int base = 3 + 8 * threadIdx.x + (threadIdx.x & 3);
+    for (int j = 0; j < 4; ++j) { want0 |= (uint32_t)lds[base + j] << (8 * j); want1 |= (uint32_t)lds[base + 4 + j] << (8 * j); }
+    const bool ok = v.x == want0 && v.y == want1;
+    const unsigned long long bal = __ballot(ok);
+    if (threadIdx.x == 0) out[6] = (float)__popcll(bal);
+}
+
+// global_load_lds_dwordx4: where do the 16 bytes of lane l land?  Fill LDS with a marker, load 64 x 16 bytes.
+__global__ void k_glds(uint32_t* out, const uint32_t* src) {
+    __shared__ uint32_t lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = 0xdeadbeefu;
+    __syncthreads();
+    const uint32_t* p = src + 4 * threadIdx.x;                  // lane l reads 16 bytes at src + 16 l
+    const unsigned ldsbase = (unsigned)(uintptr_t)lds + 64;     // land at byte 64
+    asm volatile("s_mov_b32 m0, %1\n s_nop 0\n global_load_lds_dwordx4 %0, off\n s_waitcnt vmcnt(0)" :: "v"(p), "s"(ldsbase) : "memory", "m0");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 64) out[i] = lds[i];
+}
+
+// ---------------------------------------------------------------- VALU rates ----
+#define KERNEL(NAME, DECL, BODY, SINK)                                              \
+    __global__ __launch_bounds__(256) void NAME(float* out, float seed) {          \
+        DECL;                                                                       \
+        for (int it = 0; it < ITERS; ++it) { BODY; }                                \
+        if (seed == -7.f) out[threadIdx.x] = (float)(SINK);                        \
+    }
+#define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+#define D_F32 float a0=seed,a1=seed+1,a2=seed+2,a3=seed+3,a4=seed+4,a5=seed+5,a6=seed+6,a7=seed+7; float b=seed*0.5f, c=seed*0.25f; unsigned u=(unsigned)seed*0x00030005u
+#define SUM (a0+a1+a2+a3+a4+a5+a6+a7)
+
+#define X_FMA32(i) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+KERNEL(k_fma_f32, D_F32, R8(X_FMA32), SUM)
+#define X_MIX(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel_hi:[1,0,0]" : "+v"(a##i) : "v"(u), "v"(c));
+KERNEL(k_fma_mix, D_F32, R8(X_MIX), SUM)
+#define X_MIXH(i) asm volatile("v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(a##i) : "v"(u), "v"(c));
+KERNEL(k_fma_mix_hi, D_F32, R8(X_MIXH), SUM)
+#define X_DOT2(i) asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(a##i) : "v"(u), "v"(c));
+KERNEL(k_dot2_f32_f16, D_F32, R8(X_DOT2), SUM)
+#define X_DOT4(i) asm volatile("v_dot4_u32_u8 %0, %1, %2, %0" : "+v"(a##i) : "v"(u), "v"(c));
+KERNEL(k_dot4_u32_u8, D_F32, R8(X_DOT4), SUM)
+#define X_SDWA(i) asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(a##i) : "v"(u), "v"(c));
+KERNEL(k_mul_f32_sdwa, D_F32, R8(X_SDWA), SUM)
+#define X_CVTUB(i) asm volatile("v_cvt_f32_ubyte1 %0, %1" : "=v"(a##i) : "v"(u));
+KERNEL(k_cvt_f32_ubyte, D_F32, R8(X_CVTUB), SUM)
+#define X_AND(i) asm volatile("v_and_b32 %0, 0xff00ff, %1" : "=v"(a##i) : "v"(u));
+KERNEL(k_and_lit, D_F32, R8(X_AND), SUM)
+#define X_BFE(i) asm volatile("v_bfe_u32 %0, %1, 8, 8" : "=v"(a##i) : "v"(u));
+KERNEL(k_bfe, D_F32, R8(X_BFE), SUM)
+#define X_ADD32(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+KERNEL(k_add_f32, D_F32, R8(X_ADD32), SUM)
+#define X_ADDU(i) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a##i) : "v"(u));
+KERNEL(k_add_u32, D_F32, R8(X_ADDU), SUM)
+
+__global__ __launch_bounds__(256) void k_pk_mul_f32(float* out, float seed) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a0 = {seed, seed + 1}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f2 b = a0 * 0.5f;
+    for (int it = 0; it < ITERS; ++it) {
+#define X_PKM(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+        R8(X_PKM)
+    }
+    f2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (seed == -7.f) out[threadIdx.x] = s.x + s.y;
+}
+__global__ __launch_bounds__(256) void k_pk_fma_f32(float* out, float seed) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    f2 a0 = {seed, seed + 1}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f2 b = a0 * 0.5f, c = a0 * 0.25f;
+    for (int it = 0; it < ITERS; ++it) {
+#define X_PK(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+        R8(X_PK)
+    }
+    f2 s = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;
+    if (seed == -7.f) out[threadIdx.x] = s.x + s.y;
+}
+// a realistic mix: the f16-denormal blend core of one pixel (12 fma_mix) against the present one (12 cvt + 6 pk_fma)
+__global__ __launch_bounds__(256) void k_core_mix(float* out, float seed) {
+    unsigned t0 = (unsigned)seed * 0x00030005u, t1 = t0 + 0x00010001u, t2 = t1 + 0x00010001u, t3 = t2 + 0x00010001u;
+    unsigned g0 = t0 >> 3, g1 = t1 >> 3, g2 = t2 >> 3, g3 = t3 >> 3;
+    float w0 = seed, w1 = seed * 0.5f, w2 = seed * 0.25f, w3 = seed * 0.125f, r = 0, g = 0, b = 0;
+    for (int it = 0; it < ITERS; ++it) {
+        asm volatile(
+            "v_fma_mix_f32 %0, %3, %11, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %7, %11, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %3, %11, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+            "v_fma_mix_f32 %0, %4, %12, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %8, %12, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %4, %12, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+            "v_fma_mix_f32 %0, %5, %13, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %9, %13, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %5, %13, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+            "v_fma_mix_f32 %0, %6, %14, %0 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %1, %10, %14, %1 op_sel_hi:[1,0,0]\n v_fma_mix_f32 %2, %6, %14, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n"
+            : "+v"(r), "+v"(g), "+v"(b) : "v"(t0), "v"(t1), "v"(t2), "v"(t3), "v"(g0), "v"(g1), "v"(g2), "v"(g3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    }
+    if (seed == -7.f) out[threadIdx.x] = r + g + b;
+}
+__global__ __launch_bounds__(256) void k_core_cvt(float* out, float seed) {
+    typedef float f2 __attribute__((ext_vector_type(2)));
+    unsigned t0 = (unsigned)seed * 0x00030005u, t1 = t0 + 0x00010001u, t2 = t1 + 0x00010001u, t3 = t2 + 0x00010001u;
+    f2 w0 = {seed, seed}, w1 = w0 * 0.5f, w2 = w0 * 0.25f, w3 = w0 * 0.125f, rg = {0, 0}, bx = {0, 0};
+    for (int it = 0; it < ITERS; ++it) {
+        f2 p0, p1, q0, q1, s0, s1, u0, u1;
+        asm volatile(
+            "v_cvt_f32_ubyte0 %0, %16\n v_cvt_f32_ubyte1 %1, %16\n v_cvt_f32_ubyte2 %2, %16\n"
+            "v_cvt_f32_ubyte0 %4, %17\n v_cvt_f32_ubyte1 %5, %17\n v_cvt_f32_ubyte2 %6, %17\n"
+            "v_cvt_f32_ubyte0 %8, %18\n v_cvt_f32_ubyte1 %9, %18\n v_cvt_f32_ubyte2 %10, %18\n"
+            "v_cvt_f32_ubyte0 %12, %19\n v_cvt_f32_ubyte1 %13, %19\n v_cvt_f32_ubyte2 %14, %19\n"
+            : "=v"(p0.x), "=v"(p0.y), "=v"(p1.x), "=v"(p1.y), "=v"(q0.x), "=v"(q0.y), "=v"(q1.x), "=v"(q1.y),
+              "=v"(s0.x), "=v"(s0.y), "=v"(s1.x), "=v"(s1.y), "=v"(u0.x), "=v"(u0.y), "=v"(u1.x), "=v"(u1.y)
+            : "v"(t0), "v"(t1), "v"(t2), "v"(t3));
+        asm volatile(
+            "v_pk_fma_f32 %0, %2, %10, %0\n v_pk_fma_f32 %1, %3, %10, %1\n v_pk_fma_f32 %0, %4, %11, %0\n v_pk_fma_f32 %1, %5, %11, %1\n"
+            "v_pk_fma_f32 %0, %6, %12, %0\n v_pk_fma_f32 %1, %7, %12, %1\n v_pk_fma_f32 %0, %8, %13, %0\n v_pk_fma_f32 %1, %9, %13, %1\n"
+            : "+v"(rg), "+v"(bx) : "v"(p0), "v"(p1), "v"(q0), "v"(q1), "v"(s0), "v"(s1), "v"(u0), "v"(u1), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    }
+    if (seed == -7.f) out[threadIdx.x] = rg.x + rg.y + bx.x + bx.y;
+}
+
+// ---------------------------------------------------------------- LDS read rates ----
+// Each wave reads its own 8 KB region; lane address = lane * STRIDE + MIS (+ rotating offset), 8 reads per iteration.
+template <int WIDTH, int STRIDE, int MIS, bool READ2>
+__global__ __launch_bounds__(256) void k_lds(float* out, float seed) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4 * 8192 + 64];
+    for (int i = threadIdx.x; i < (4 * 8192 + 64) / 4; i += 256) reinterpret_cast<uint32_t*>(lds)[i] = i;
+    __syncthreads();
+    const unsigned wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned addr = (unsigned)(uintptr_t)lds + wave * 8192 + lane * STRIDE + MIS;
+    uint32_t acc = 0;
+    for (int it = 0; it < ITERS; ++it) {
+        if constexpr (WIDTH == 4 && !READ2) {
+            uint32_t v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read_b32 %0, %8\n ds_read_b32 %1, %8 offset:16\n ds_read_b32 %2, %8 offset:32\n ds_read_b32 %3, %8 offset:48\n"
+                         "ds_read_b32 %4, %8 offset:64\n ds_read_b32 %5, %8 offset:80\n ds_read_b32 %6, %8 offset:96\n ds_read_b32 %7, %8 offset:112\n s_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7) : "v"(addr));
+            acc += v0 ^ v1 ^ v2 ^ v3 ^ v4 ^ v5 ^ v6 ^ v7;
+        } else if constexpr (WIDTH == 4 && READ2) {      // read2_b32: two dwords 1 row (256 B) apart
+            uint2 v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read2_b32 %0, %8 offset0:0 offset1:64\n ds_read2_b32 %1, %8 offset0:4 offset1:68\n ds_read2_b32 %2, %8 offset0:8 offset1:72\n ds_read2_b32 %3, %8 offset0:12 offset1:76\n"
+                         "ds_read2_b32 %4, %8 offset0:16 offset1:80\n ds_read2_b32 %5, %8 offset0:20 offset1:84\n ds_read2_b32 %6, %8 offset0:24 offset1:88\n ds_read2_b32 %7, %8 offset0:28 offset1:92\n s_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7) : "v"(addr));
+            acc += v0.x ^ v1.y ^ v2.x ^ v3.y ^ v4.x ^ v5.y ^ v6.x ^ v7.y;
+        } else if constexpr (WIDTH == 8 && !READ2) {
+            uint2 v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read_b64 %0, %8\n ds_read_b64 %1, %8 offset:16\n ds_read_b64 %2, %8 offset:32\n ds_read_b64 %3, %8 offset:48\n"
+                         "ds_read_b64 %4, %8 offset:64\n ds_read_b64 %5, %8 offset:80\n ds_read_b64 %6, %8 offset:96\n ds_read_b64 %7, %8 offset:112\n s_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7) : "v"(addr));
+            acc += v0.x ^ v1.y ^ v2.x ^ v3.y ^ v4.x ^ v5.y ^ v6.x ^ v7.y;
+        } else if constexpr (WIDTH == 8 && READ2) {      // read2_b64: two qwords 1 row (1024 B) apart
+            uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read2_b64 %0, %8 offset0:0 offset1:128\n ds_read2_b64 %1, %8 offset0:2 offset1:130\n ds_read2_b64 %2, %8 offset0:4 offset1:132\n ds_read2_b64 %3, %8 offset0:6 offset1:134\n"
+                         "ds_read2_b64 %4, %8 offset0:8 offset1:136\n ds_read2_b64 %5, %8 offset0:10 offset1:138\n ds_read2_b64 %6, %8 offset0:12 offset1:140\n ds_read2_b64 %7, %8 offset0:14 offset1:142\n s_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7) : "v"(addr));
+            acc += v0.x ^ v1.y ^ v2.z ^ v3.w ^ v4.x ^ v5.y ^ v6.z ^ v7.w;
+        } else {
+            uint4 v0, v1, v2, v3, v4, v5, v6, v7;
+            asm volatile("ds_read_b128 %0, %8\n ds_read_b128 %1, %8 offset:16\n ds_read_b128 %2, %8 offset:32\n ds_read_b128 %3, %8 offset:48\n"
+                         "ds_read_b128 %4, %8 offset:64\n ds_read_b128 %5, %8 offset:80\n ds_read_b128 %6, %8 offset:96\n ds_read_b128 %7, %8 offset:112\n s_waitcnt lgkmcnt(0)"
+                         : "=v"(v0), "=v"(v1), "=v"(v2), "=v"(v3), "=v"(v4), "=v"(v5), "=v"(v6), "=v"(v7) : "v"(addr));
+            acc += v0.x ^ v1.y ^ v2.z ^ v3.w ^ v4.x ^ v5.y ^ v6.z ^ v7.w;
+        }
+    }
+    if (seed == -7.f) out[threadIdx.x] = (float)acc;
+}
+
+struct Case { const char* name; void (*k)(float*, float); int per_iter; };
+
+int main() {
+    float* out; CK(hipMalloc(&out, 1 << 16));
+    uint32_t* din; CK(hipMalloc(&din, 4096));
+    uint32_t hin[1024];
+    for (int i = 0; i < 1024; ++i) hin[i] = 0x1000000u + i;
+    hin[0] = 0x03ff7f11u;
+    CK(hipMemcpy(din, hin, sizeof hin, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_semantics, dim3(1), dim3(64), 0, 0, out, din);
+    float h[8]; CK(hipMemcpy(h, out, sizeof h, hipMemcpyDeviceToHost));
+    printf("semantics (pixel bytes 17,127,255,3):\n");
+    printf("  fma_mix f16-denormal lo * 2^24 = %g (want 17), hi = %g (want 255)\n", h[0], h[1]);
+    printf("  dot2_f32_f16 denormal (17*1 + 255*2) = %g (want 527)\n", h[2]);
+    printf("  mul_f32_sdwa BYTE_1 denormal = %g (want 127)\n", h[3]);
+    printf("  cvt_f32_ubyte3 = %g (want 3), pk_mul = %g (want 76)\n", h[4], h[5]);
+    printf("  misaligned ds_read_b64 lanes correct: %g / 64\n", h[6]);
+    hin[0] = 0x1000000u;
+    CK(hipMemcpy(din, hin, sizeof hin, hipMemcpyHostToDevice));
+    uint32_t* dout32 = reinterpret_cast<uint32_t*>(out);
+    hipLaunchKernelGGL(k_glds, dim3(1), dim3(64), 0, 0, dout32, din);
+    uint32_t hl[1024]; CK(hipMemcpy(hl, dout32, sizeof hl, hipMemcpyDeviceToHost));
+    int first = -1, last = -1, inorder = 1;
+    for (int i = 0; i < 1024; ++i) if (hl[i] != 0xdeadbeefu) { if (first < 0) first = i; last = i; }
+    for (int i = first; i <= last && first >= 0; ++i) if (hl[i] != 0x1000000u + (i - first)) inorder = 0;
+    printf("  global_load_lds_dwordx4: dwords written %d..%d (want 16..271), contiguous lane-major copy: %s\n", first, last, inorder ? "yes" : "NO");
+    if (!inorder && first >= 0) { printf("   first 12 dwords:"); for (int i = first; i < first + 12; ++i) printf(" %x", hl[i]); printf("\n"); }
+
+    Case cases[] = {
+        {"v_fma_f32", k_fma_f32, 8}, {"v_add_f32", k_add_f32, 8}, {"v_add_u32", k_add_u32, 8}, {"v_pk_fma_f32", k_pk_fma_f32, 8}, {"v_pk_mul_f32", k_pk_mul_f32, 8},
+        {"v_fma_mix_f32 (lo)", k_fma_mix, 8}, {"v_fma_mix_f32 (hi)", k_fma_mix_hi, 8}, {"v_dot2_f32_f16", k_dot2_f32_f16, 8},
+        {"v_dot4_u32_u8", k_dot4_u32_u8, 8}, {"v_mul_f32_sdwa", k_mul_f32_sdwa, 8}, {"v_cvt_f32_ubyte1", k_cvt_f32_ubyte, 8},
+        {"v_and_b32 literal", k_and_lit, 8}, {"v_bfe_u32", k_bfe, 8},
+        {"core: 12 fma_mix", k_core_mix, 12}, {"core: 12 cvt + 8 pk_fma", k_core_cvt, 20},
+        {"ds_read_b32 s4", k_lds<4, 4, 0, false>, 8}, {"ds_read_b32 s8", k_lds<4, 8, 0, false>, 8}, {"ds_read_b32 s16", k_lds<4, 16, 0, false>, 8},
+        {"ds_read2_b32 s4", k_lds<4, 4, 0, true>, 8}, {"ds_read2_b32 s16", k_lds<4, 16, 0, true>, 8},
+        {"ds_read_b64 s8", k_lds<8, 8, 0, false>, 8}, {"ds_read_b64 s8 mis1", k_lds<8, 8, 1, false>, 8}, {"ds_read_b64 s8 mis4", k_lds<8, 8, 4, false>, 8},
+        {"ds_read_b64 s3 mis0", k_lds<8, 3, 0, false>, 8}, {"ds_read_b64 s16", k_lds<8, 16, 0, false>, 8},
+        {"ds_read2_b64 s8", k_lds<8, 8, 0, true>, 8}, {"ds_read2_b64 s16", k_lds<8, 16, 0, true>, 8},
+        {"ds_read_b128 s16", k_lds<16, 16, 0, false>, 8},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int blocks = 256 * 4;  // 4 blocks of 4 waves per CU (LDS: 32 KB per block)
+    double base = 0;
+    for (auto& c : cases) {
+        hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+        CK(hipEventRecord(e0));
+        const int reps = 20;
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, out, 1.0f);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        const double instr_per_simd = 4.0 * ITERS * c.per_iter;       // 4 waves per SIMD
+        const double t = ms / instr_per_simd;
+        if (base == 0) base = t;
+        printf("%-26s %8.4f ms   %6.2f x v_fma_f32 per wave-instr  (%.2f cycles @2.4GHz)\n", c.name, ms, t / base, t * 1e-3 * 2.4e9);
+    }
+    return 0;
+}

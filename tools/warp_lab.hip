@@ -182,9 +182,9 @@ int main(int argc, char** argv) {
                                          G.y0 + G.h - 1, G.h, G.w, SH, SW, RWH_BILINEAR, dst, RWH_U8, (int64_t)G.w * G.h * 3, 0, G.h, RWH_WARP_EXACT, nullptr); }},
             {"fast u8 px4", [&] { return fast(0, 1); }},
             {"fast u8 px8", [&] { return fast(1, 1); }},
-            {"fast u8 px8 shape 128x4", [&] { setenv("RWH_WARP_SHAPE", "7", 1); int r = fast(1, 1); unsetenv("RWH_WARP_SHAPE"); return r; }},
-            {"fast u8 px8 shape 64x8", [&] { setenv("RWH_WARP_SHAPE", "6", 1); int r = fast(1, 1); unsetenv("RWH_WARP_SHAPE"); return r; }},
-            {"fast u8 px8 shape 32x16", [&] { setenv("RWH_WARP_SHAPE", "5", 1); int r = fast(1, 1); unsetenv("RWH_WARP_SHAPE"); return r; }},
+            {"fast u8 px8 shape 128x4", [&] { rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 7); int r = fast(1, 1); rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 0); return r; }},
+            {"fast u8 px8 shape 64x8", [&] { rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 6); int r = fast(1, 1); rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 0); return r; }},
+            {"fast u8 px8 shape 32x16", [&] { rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 5); int r = fast(1, 1); rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 0); return r; }},
             {"twin: px8 access pattern, no ALU", [&] { return fast(2, 0); }},
             {"twin: px8 access pattern + 220 FMA", [&] { return fast(2, 1); }},
             {"twin: px8 access pattern + 440 FMA", [&] { return fast(2, 2); }},
