@@ -53,7 +53,8 @@ RWH_API const char* rwh_strerror(int code);
 
 /*
  * Lab / test hook, not part of the data path: pins a launch heuristic process-wide (value 0 = back to the library's
- * own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
+ * own choice).  RWH_TUNE_WARP_SHAPE: kernel kind of the fast bilinear path -- 5, 6, 7 = wave-private slabs with 32x16 / 64x8 / 128x4
+ * patches, 22, 23 = the block-tile kernel with 64x8 / 128x4 patches (uint8 output; ignored where it cannot serve); RWH_TUNE_SCORE_HPW:
  * hypotheses per wavefront of the scorer (1..64).  Results never depend on either (tests/test_gpu_parity.py).
  */
 enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1 };

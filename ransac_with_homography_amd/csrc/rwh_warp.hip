@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <vector>
 #include "rwh_warp_rgb8.h"
+#include "rwh_warp_tile.h"
 
 namespace rwh {
 
@@ -337,8 +338,31 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // texels).  The choice is a function of the homography and the WHOLE output grid only -- never of the row shard or the
 // batch -- so that shards, batches and single launches of the same warp run the same arithmetic and agree bit for bit.
 // rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 5|6|7) overrides (tests, lab).
-static int choose_shape(const FastArgs& a) {
-    if (g_force_warp_shape) return g_force_warp_shape;
+// Kernel kinds of the 8-px family: 5 / 6 / 7 = warp_rgb8_fast8 with that patch shape (wave-private slabs);
+// KIND_TILE + 6 / 7 = the tile kernel (rwh_warp_tile.h: block-shared raw-byte slab filled by DMA) with that patch shape.
+constexpr int KIND_TILE = 16;
+
+// The tile kernel serves a warp (uint8 output) when the DMA's 16-byte alignment assumptions hold and the 128 x 16 tile
+// footprints fit its window on >= 90 % of a 5 x 5 sample of tile positions.  Function of the homography and the WHOLE
+// output grid only (see choose_shape).
+static bool tile_serves(const FastArgs& a) {
+    if (((uintptr_t)a.src & 15u) || (a.src_img_stride & 15) || ((3 * a.src_w) & 15)) return false;
+    int seen = 0, fit = 0;
+    for (int i = 0; i < 5; ++i)
+        for (int j = 0; j < 5; ++j) {
+            const double r = (a.out_h > 16 ? (a.out_h - 16) * (i / 4.0) : 0.0), c = (a.out_w > 128 ? (a.out_w - 128) * (j / 4.0) : 0.0);
+            ++seen; fit += tile_fits(a, __builtin_floor(r), __builtin_floor(c));
+        }
+    return 10 * fit >= 9 * seen;
+}
+
+static int choose_shape(const FastArgs& a, bool tile_allowed = false) {
+    if (g_force_warp_shape) {
+        if (g_force_warp_shape < KIND_TILE) return g_force_warp_shape;
+        if (tile_allowed && !(((uintptr_t)a.src & 15u) || (a.src_img_stride & 15) || ((3 * a.src_w) & 15))) return g_force_warp_shape;
+    } else if (tile_allowed && tile_serves(a)) {
+        return KIND_TILE + 6;
+    }
     int best = 0;
     double best_lines = 1e300;
     const int order[3] = {6, 7, 5};
@@ -399,18 +423,21 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.gx0 = w.x0; a.gstep_x = w.step_x; a.gx_last = w.x_last; a.gy0 = w.y0; a.gstep_y = w.step_y; a.gy_last = w.y_last;
     a.out_h = w.out_h;
     // patch shape: the host's choice per homography; with one homography per image the images are grouped by shape
-    int shape = 0, shapes[3] = {0, 0, 0};
+    int shape = 0;
+    bool kinds[32] = {};
     std::vector<int> shape_of(n_h > 1 ? n_h : 0);
+    const bool tile_allowed = px8 && !nn && !custom && dst_dtype == RWH_U8;
     if (px8) {
         for (int i = 0; i < n_h; ++i) {
             fill_coef(a.c, ih + 9 * i, x0, step_x, y0, step_y);
-            shape = choose_shape(a);
-            if (n_h > 1) { shape_of[i] = shape; shapes[shape - 5] = 1; }
+            shape = choose_shape(a, tile_allowed);
+            if (n_h > 1) { shape_of[i] = shape; kinds[shape] = true; }
         }
     }
+    const bool tile = shape >= KIND_TILE;                          // (n_h == 1: the launch's kernel kind)
     fill_coef(a.c, ih, x0, step_x, y0, step_y);
-    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << shape) / 8 : 1;
-    if (px8) fill_offsets(a.c, shape, pstr);
+    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << (shape & 7)) / 8 : 1;
+    if (px8) fill_offsets(a.c, shape & 7, pstr);
     for (int j = 1; j <= 3; ++j) { a.dxs[j - 1][0] = j * a.c.cx[2]; a.dxs[j - 1][1] = j * a.c.cy[2]; a.dxs[j - 1][2] = j * a.c.cw[2]; }
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
@@ -434,6 +461,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         void (*kern)(const FastArgs) = custom;
         if (!kern) {
             if (nn) kern = shape == 7 ? warp_rgb8_nn<7> : shape == 6 ? warp_rgb8_nn<6> : warp_rgb8_nn<5>;
+            else if (tile) kern = shape == KIND_TILE + 7 ? warp_rgb8_tile<7> : warp_rgb8_tile<6>;
             else if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
             else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
             else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
@@ -443,18 +471,20 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         return check_launch();
     }
     // one homography per image: per shape, TAB_N images per launch with their coefficients as a second kernel argument
-    for (int sh = 7; sh >= 5; --sh) {
-        if (!shapes[sh - 5]) continue;
+    for (int kind = 31; kind >= 5; --kind) {
+        if (!kinds[kind]) continue;
+        const int sh = kind & 7;
         const int ps = u8 ? 1 : (1 << sh) / 8;
         void (*kern)(const FastArgs, const CoefTab);
         if (nn) kern = sh == 7 ? warp_rgb8_nn_tab<7> : sh == 6 ? warp_rgb8_nn_tab<6> : warp_rgb8_nn_tab<5>;
+        else if (kind >= KIND_TILE) kern = sh == 7 ? warp_rgb8_tile_tab<7> : warp_rgb8_tile_tab<6>;
         else if (sh == 7) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 7> : warp_rgb8_fast8_tab<float, 7>;
         else if (sh == 6) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 6> : warp_rgb8_fast8_tab<float, 6>;
         else kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 5> : warp_rgb8_fast8_tab<float, 5>;
         CoefTab tab;
         int count = 0;
         for (int i = 0; i <= n_h; ++i) {
-            if (i < n_h && shape_of[i] == sh) {
+            if (i < n_h && shape_of[i] == kind) {
                 fill_coef(tab.e[count], ih + 9 * i, x0, step_x, y0, step_y);
                 fill_offsets(tab.e[count], sh, ps);
                 tab.e[count++].image = i;

@@ -1,0 +1,33 @@
+"""Developer probe: time the uint8 bilinear warp of the BASELINE workload per kernel kind (rwh_lab_tune).
+   python tools/warp_quick.py [kinds...]      kinds: 0 auto, 5/6/7 wave-private patches, 22/23 tile kernel"""
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ransac_with_homography_amd import _lib, kernels
+from ransac_with_homography_amd import homography as hg
+H_S = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+frames = int(os.environ.get("FRAMES", "32"))
+W, Hh = (int(v) for v in os.environ.get("SRC", "3840x2160").split("x"))
+dev = _lib.require_gpu()
+g = torch.Generator(device="cpu").manual_seed(1)
+src = torch.randint(0, 256, (frames, Hh, W, 3), dtype=torch.uint8, generator=g).to(dev)
+mx, my, ow, oh = hg._bounds(Hh, W, H_S, 0)
+grid = kernels.Grid(mx, mx + ow - 1, ow, my, my + oh - 1, oh)
+inv = np.linalg.inv(H_S)
+out = torch.empty((frames, oh, ow, 3), dtype=torch.uint8, device=dev)
+lib = _lib.load()
+ref = None
+for kind in [int(a) for a in sys.argv[1:]] or [6, 22, 23]:
+    assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, kind) == 0
+    for _ in range(60): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    n = 40
+    for _ in range(n): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / n
+    by = frames * (Hh * W * 3 + oh * ow * 3)
+    same = "" if ref is None else (" identical to first kind: %s" % bool(torch.equal(ref, out)))
+    if ref is None: ref = out.clone()
+    print("kind %2d  %.4f ms per %d frames = %.2f us/frame  %.0f GB/s = %.3f of 8 TB/s%s" % (kind, ms, frames, ms * 1e3 / frames, by / ms / 1e6, by / ms / 1e6 / 8000, same), flush=True)
