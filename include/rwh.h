@@ -53,8 +53,7 @@ RWH_API const char* rwh_strerror(int code);
 
 /*
  * Lab / test hook, not part of the data path: pins a launch heuristic process-wide (value 0 = back to the library's
- * own choice).  RWH_TUNE_WARP_SHAPE: kernel kind of the fast bilinear path -- 5, 6, 7 = wave-private slabs with 32x16 / 64x8 / 128x4
- * patches, 22, 23 = the block-tile kernel with 64x8 / 128x4 patches (uint8 output; ignored where it cannot serve); RWH_TUNE_SCORE_HPW:
+ * own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
  * hypotheses per wavefront of the scorer (1..64).  Results never depend on either (tests/test_gpu_parity.py).
  */
 enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1 };
@@ -100,6 +99,16 @@ RWH_API int rwh_warp_backward(const void* d_src, int src_h, int src_w, int chann
                       int out_h, int out_w, int bound_h, int bound_w, int interp,
                       void* d_dst, int dst_dtype, int64_t dst_image_stride,
                       int row_begin, int row_end, unsigned flags, void* stream);
+
+/*
+ * Which kernel rwh_warp_backward would launch for these arguments (same dispatch code, nothing is launched, no device
+ * pointer is needed): writes the kernel's name as rocprofv3 prints it, e.g. "rwh::warp_rgb8_fast8<unsigned char, 6>"
+ * (with one homography per image: the first group's kernel).  For reports (bench.py's roofline.kernel) and tests.
+ */
+RWH_API int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, int batch, const double* inv_h, int n_h,
+                  double x0, double step_x, double x_last, double y0, double step_y, double y_last,
+                  int out_h, int out_w, int bound_h, int bound_w, int interp, int dst_dtype,
+                  int row_begin, int row_end, unsigned flags, char* kernel_name, int name_len);
 
 /*
  * Batched 4-point DLT hypothesis generator.  Replaces K calls of

@@ -20,7 +20,7 @@ RWH_BATCH_DEVICE_SAMPLING = 1
 RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW = 0, 1
 
 # every symbol include/rwh.h declares (tests check the library exports them all)
-EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_warp_backward", "rwh_dlt4_batched",
+EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_warp_backward", "rwh_warp_plan", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama")
 
 
@@ -50,6 +50,9 @@ def _bind(lib):
                                       f64, f64, f64, f64, f64, f64,           # x0 step_x x_last y0 step_y y_last
                                       i32, i32, i32, i32, i32,                # out_h out_w bound_h bound_w interp
                                       vp, i32, i64, i32, i32, u32, vp]        # dst dtype stride row_begin row_end flags stream
+    lib.rwh_warp_plan.restype = i32
+    lib.rwh_warp_plan.argtypes = [i32, i32, i32, i32, i32, c.POINTER(f64), i32, f64, f64, f64, f64, f64, f64,
+                                  i32, i32, i32, i32, i32, i32, i32, i32, u32, c.c_char_p, i32]
     lib.rwh_dlt4_batched.restype = i32
     lib.rwh_dlt4_batched.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     lib.rwh_score_count.restype = i32

@@ -15,12 +15,23 @@
 //     of output tile rows: vertically adjacent tiles share source rows in one L2;
 //   * no MFMA: there is no dense contraction in this path.
 #include "rwh_common.h"
+#include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include "rwh_warp_rgb8.h"
-#include "rwh_warp_tile.h"
 
 namespace rwh {
+
+// rwh_warp_plan: the dispatch below runs as usual but, instead of launching, every launch site records the kernel it
+// would have launched (the names are the demangled kernel names rocprofv3 prints).
+static thread_local char* g_plan_buf = nullptr;
+static thread_local int g_plan_len = 0;
+static bool plan_only(const char* fmt, const char* a = "", int b = 0, const char* c = "", int d = 0) {
+    if (!g_plan_buf) return false;
+    if (g_plan_buf[0] == 0) snprintf(g_plan_buf, (size_t)g_plan_len, fmt, a, b, c, d);   // the first launch = the dominant kernel
+    return true;
+}
+template <typename T> constexpr const char* tname() { return sizeof(T) == 1 ? "unsigned char" : sizeof(T) == 4 ? "float" : "double"; }
 
 struct WarpArgs {
     const unsigned char* src;
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
     if (whole) __builtin_memcpy(drow, packed, sizeof(packed));
 }
 
-template <typename K> int launch(K kernel, const WarpArgs& a, hipStream_t s);
+template <typename K> int launch(K kernel, const WarpArgs& a, hipStream_t s, const char* family, const char* src, int c, const char* dst, int interp);
 
 // ================================================================================================
 // Exact kernel (flag RWH_WARP_EXACT): the reference's float64 arithmetic, operation by operation, so that
@@ -299,16 +310,19 @@ template <typename SrcT, int C>
 int dispatch_exact(const WarpArgs& a, int interp, int dst_dtype, hipStream_t s) {
     if (interp == RWH_NEAREST) {
         if (dst_dtype != elem<SrcT>::dtype) return RWH_E_UNSUPPORTED;
-        return launch(warp_exact<SrcT, C, SrcT, RWH_NEAREST>, a, s);
+        return launch(warp_exact<SrcT, C, SrcT, RWH_NEAREST>, a, s, "warp_exact", tname<SrcT>(), C, tname<SrcT>(), RWH_NEAREST);
     }
-    if (dst_dtype == RWH_F64) return launch(warp_exact<SrcT, C, double, RWH_BILINEAR>, a, s);
-    if (dst_dtype == RWH_U8) return launch(warp_exact<SrcT, C, unsigned char, RWH_BILINEAR>, a, s);
+    if (dst_dtype == RWH_F64) return launch(warp_exact<SrcT, C, double, RWH_BILINEAR>, a, s, "warp_exact", tname<SrcT>(), C, "double", RWH_BILINEAR);
+    if (dst_dtype == RWH_U8) return launch(warp_exact<SrcT, C, unsigned char, RWH_BILINEAR>, a, s, "warp_exact", tname<SrcT>(), C, "unsigned char", RWH_BILINEAR);
     return RWH_E_UNSUPPORTED;
 }
 
 // ---- host side ---------------------------------------------------------------------------------
 template <typename K>
-int launch(K kernel, const WarpArgs& a, hipStream_t s) {
+int launch(K kernel, const WarpArgs& a, hipStream_t s, const char* family, const char* src, int c, const char* dst, int interp) {
+    char fmt[96];
+    snprintf(fmt, sizeof fmt, "rwh::%s<%%s, %%d, %%s, %%d>", family);
+    if (plan_only(fmt, src, c, dst, interp)) return RWH_OK;
     const unsigned grid = 8u * a.cpx;
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, s, a);
     return check_launch();
@@ -318,10 +332,10 @@ template <typename SrcT, int C>
 int dispatch(const WarpArgs& a, int interp, int dst_dtype, hipStream_t s) {
     if (interp == RWH_NEAREST) {
         if (dst_dtype != elem<SrcT>::dtype) return RWH_E_UNSUPPORTED;
-        return launch(warp_generic<SrcT, C, SrcT, RWH_NEAREST>, a, s);
+        return launch(warp_generic<SrcT, C, SrcT, RWH_NEAREST>, a, s, "warp_generic", tname<SrcT>(), C, tname<SrcT>(), RWH_NEAREST);
     }
-    if (dst_dtype == RWH_F32) return launch(warp_generic<SrcT, C, float, RWH_BILINEAR>, a, s);
-    if (dst_dtype == RWH_U8) return launch(warp_generic<SrcT, C, unsigned char, RWH_BILINEAR>, a, s);
+    if (dst_dtype == RWH_F32) return launch(warp_generic<SrcT, C, float, RWH_BILINEAR>, a, s, "warp_generic", tname<SrcT>(), C, "float", RWH_BILINEAR);
+    if (dst_dtype == RWH_U8) return launch(warp_generic<SrcT, C, unsigned char, RWH_BILINEAR>, a, s, "warp_generic", tname<SrcT>(), C, "unsigned char", RWH_BILINEAR);
     return RWH_E_UNSUPPORTED;
 }
 
@@ -338,31 +352,8 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // texels).  The choice is a function of the homography and the WHOLE output grid only -- never of the row shard or the
 // batch -- so that shards, batches and single launches of the same warp run the same arithmetic and agree bit for bit.
 // rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 5|6|7) overrides (tests, lab).
-// Kernel kinds of the 8-px family: 5 / 6 / 7 = warp_rgb8_fast8 with that patch shape (wave-private slabs);
-// KIND_TILE + 6 / 7 = the tile kernel (rwh_warp_tile.h: block-shared raw-byte slab filled by DMA) with that patch shape.
-constexpr int KIND_TILE = 16;
-
-// The tile kernel serves a warp (uint8 output) when the DMA's 16-byte alignment assumptions hold and the 128 x 16 tile
-// footprints fit its window on >= 90 % of a 5 x 5 sample of tile positions.  Function of the homography and the WHOLE
-// output grid only (see choose_shape).
-static bool tile_serves(const FastArgs& a) {
-    if (((uintptr_t)a.src & 15u) || (a.src_img_stride & 15) || ((3 * a.src_w) & 15)) return false;
-    int seen = 0, fit = 0;
-    for (int i = 0; i < 5; ++i)
-        for (int j = 0; j < 5; ++j) {
-            const double r = (a.out_h > 16 ? (a.out_h - 16) * (i / 4.0) : 0.0), c = (a.out_w > 128 ? (a.out_w - 128) * (j / 4.0) : 0.0);
-            ++seen; fit += tile_fits(a, __builtin_floor(r), __builtin_floor(c));
-        }
-    return 10 * fit >= 9 * seen;
-}
-
-static int choose_shape(const FastArgs& a, bool tile_allowed = false) {
-    if (g_force_warp_shape) {
-        if (g_force_warp_shape < KIND_TILE) return g_force_warp_shape;
-        if (tile_allowed && !(((uintptr_t)a.src & 15u) || (a.src_img_stride & 15) || ((3 * a.src_w) & 15))) return g_force_warp_shape;
-    } else if (tile_allowed && tile_serves(a)) {
-        return KIND_TILE + 6;
-    }
+static int choose_shape(const FastArgs& a) {
+    if (g_force_warp_shape) return g_force_warp_shape;
     int best = 0;
     double best_lines = 1e300;
     const int order[3] = {6, 7, 5};
@@ -373,9 +364,9 @@ static int choose_shape(const FastArgs& a, bool tile_allowed = false) {
         for (int i = 0; i < 5; ++i)
             for (int j = 0; j < 5; ++j) {
                 const double r = (a.out_h > ph ? (a.out_h - ph) * (i / 4.0) : 0.0), c = (a.out_w > pw ? (a.out_w - pw) * (j / 4.0) : 0.0);
-                long long ch; double ln;
-                if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &ch, &ln)) continue;   // horizon: gathers anyway
-                ++seen; fit += ch <= F8_CHUNKS; lines_sum += ln;
+                long long nr, nt; double ln;
+                if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &nr, &nt, &ln)) continue;   // horizon: gathers anyway
+                ++seen; fit += f8_window_fits(lp, nr, nt); lines_sum += ln;
             }
         if (seen == 0) return 6;
         if (10 * fit < 9 * seen) continue;
@@ -423,21 +414,18 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.gx0 = w.x0; a.gstep_x = w.step_x; a.gx_last = w.x_last; a.gy0 = w.y0; a.gstep_y = w.step_y; a.gy_last = w.y_last;
     a.out_h = w.out_h;
     // patch shape: the host's choice per homography; with one homography per image the images are grouped by shape
-    int shape = 0;
-    bool kinds[32] = {};
+    int shape = 0, shapes[3] = {0, 0, 0};
     std::vector<int> shape_of(n_h > 1 ? n_h : 0);
-    const bool tile_allowed = px8 && !nn && !custom && dst_dtype == RWH_U8;
     if (px8) {
         for (int i = 0; i < n_h; ++i) {
             fill_coef(a.c, ih + 9 * i, x0, step_x, y0, step_y);
-            shape = choose_shape(a, tile_allowed);
-            if (n_h > 1) { shape_of[i] = shape; kinds[shape] = true; }
+            shape = choose_shape(a);
+            if (n_h > 1) { shape_of[i] = shape; shapes[shape - 5] = 1; }
         }
     }
-    const bool tile = shape >= KIND_TILE;                          // (n_h == 1: the launch's kernel kind)
     fill_coef(a.c, ih, x0, step_x, y0, step_y);
-    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << (shape & 7)) / 8 : 1;
-    if (px8) fill_offsets(a.c, shape & 7, pstr);
+    const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << shape) / 8 : 1;
+    if (px8) fill_offsets(a.c, shape, pstr);
     for (int j = 1; j <= 3; ++j) { a.dxs[j - 1][0] = j * a.c.cx[2]; a.dxs[j - 1][1] = j * a.c.cy[2]; a.dxs[j - 1][2] = j * a.c.cw[2]; }
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
@@ -461,30 +449,31 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         void (*kern)(const FastArgs) = custom;
         if (!kern) {
             if (nn) kern = shape == 7 ? warp_rgb8_nn<7> : shape == 6 ? warp_rgb8_nn<6> : warp_rgb8_nn<5>;
-            else if (tile) kern = shape == KIND_TILE + 7 ? warp_rgb8_tile<7> : warp_rgb8_tile<6>;
             else if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
             else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
             else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
             else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
         }
+        if (custom ? false : nn ? plan_only("rwh::warp_rgb8_nn<%.0s%d>", "", shape)
+                          : !px8 ? plan_only("rwh::warp_rgb8_fast<%s>", u8 ? "unsigned char" : "float")
+                                 : plan_only("rwh::warp_rgb8_fast8<%s, %d>", u8 ? "unsigned char" : "float", shape))
+            return RWH_OK;
         hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a);
         return check_launch();
     }
     // one homography per image: per shape, TAB_N images per launch with their coefficients as a second kernel argument
-    for (int kind = 31; kind >= 5; --kind) {
-        if (!kinds[kind]) continue;
-        const int sh = kind & 7;
+    for (int sh = 7; sh >= 5; --sh) {
+        if (!shapes[sh - 5]) continue;
         const int ps = u8 ? 1 : (1 << sh) / 8;
         void (*kern)(const FastArgs, const CoefTab);
         if (nn) kern = sh == 7 ? warp_rgb8_nn_tab<7> : sh == 6 ? warp_rgb8_nn_tab<6> : warp_rgb8_nn_tab<5>;
-        else if (kind >= KIND_TILE) kern = sh == 7 ? warp_rgb8_tile_tab<7> : warp_rgb8_tile_tab<6>;
         else if (sh == 7) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 7> : warp_rgb8_fast8_tab<float, 7>;
         else if (sh == 6) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 6> : warp_rgb8_fast8_tab<float, 6>;
         else kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 5> : warp_rgb8_fast8_tab<float, 5>;
         CoefTab tab;
         int count = 0;
         for (int i = 0; i <= n_h; ++i) {
-            if (i < n_h && shape_of[i] == kind) {
+            if (i < n_h && shape_of[i] == sh) {
                 fill_coef(tab.e[count], ih + 9 * i, x0, step_x, y0, step_y);
                 fill_offsets(tab.e[count], sh, ps);
                 tab.e[count++].image = i;
@@ -492,6 +481,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
             if (count == TAB_N || (i == n_h && count > 0)) {
                 for (int k = count; k < TAB_N; ++k) tab.e[k] = tab.e[0];
                 if (!geometry(count)) return RWH_E_UNSUPPORTED;
+                if (nn ? plan_only("rwh::warp_rgb8_nn_tab<%.0s%d>", "", sh) : plan_only("rwh::warp_rgb8_fast8_tab<%s, %d>", u8 ? "unsigned char" : "float", sh)) { count = 0; continue; }
                 hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a, tab);
                 if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
                 count = 0;
@@ -524,7 +514,7 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     if ((size_t)src_h * (size_t)src_w * channels * esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    if (flags & RWH_WARP_ZERO_ORIGIN) {  // one tiny launch for the whole batch (memsets cost ~4 us each)
+    if ((flags & RWH_WARP_ZERO_ORIGIN) && !g_plan_buf) {  // one tiny launch for the whole batch (memsets cost ~4 us each)
         hipLaunchKernelGGL(zero_origin_kernel, dim3((batch + 255) / 256), dim3(256), 0, s,
                            const_cast<unsigned char*>(static_cast<const unsigned char*>(d_src)), (long long)src_image_stride,
                            batch, (int)(channels * esz));
@@ -601,4 +591,21 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     if (src_dtype == RWH_U8) return channels == 3 ? dispatch<unsigned char, 3>(a, interp, dst_dtype, s)
                                                   : dispatch<unsigned char, 4>(a, interp, dst_dtype, s);
     return channels == 3 ? dispatch<float, 3>(a, interp, dst_dtype, s) : dispatch<float, 4>(a, interp, dst_dtype, s);
+}
+
+extern "C" int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, int batch, const double* inv_h, int n_h,
+                             double x0, double step_x, double x_last, double y0, double step_y, double y_last,
+                             int out_h, int out_w, int bound_h, int bound_w, int interp, int dst_dtype,
+                             int row_begin, int row_end, unsigned flags, char* kernel_name, int name_len) {
+    if (!kernel_name || name_len <= 0) return RWH_E_INVALID;
+    kernel_name[0] = 0;
+    rwh::g_plan_buf = kernel_name; rwh::g_plan_len = name_len;
+    static unsigned char dummy[16];   // never dereferenced: every launch site returns before touching the device
+    const int64_t src_stride = (int64_t)src_h * src_w * channels * (src_dtype == RWH_U8 ? 1 : 4);
+    const int64_t dst_stride = (int64_t)(row_end - row_begin) * out_w * channels * (dst_dtype == RWH_U8 ? 1 : dst_dtype == RWH_F32 ? 4 : 8);
+    const int st = rwh_warp_backward(dummy, src_h, src_w, channels, src_dtype, src_stride, batch, inv_h, n_h, x0, step_x, x_last, y0,
+                                     step_y, y_last, out_h, out_w, bound_h, bound_w, interp, dummy, dst_dtype, dst_stride, row_begin,
+                                     row_end, flags, nullptr);
+    rwh::g_plan_buf = nullptr; rwh::g_plan_len = 0;
+    return st;
 }

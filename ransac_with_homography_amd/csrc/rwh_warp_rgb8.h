@@ -422,17 +422,39 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
 //   LOG_PW = 6    64 x 8  patches, 2 x 2                     -- up to ~10 degrees
 //   LOG_PW = 5    32 x 16 patches, 4 side by side            -- any rotation at scale ~1
 //
-// The footprint capacity is an AREA, not a shape: a wave stages any footprint of `nrows` source rows x C 12-byte
-// chunks (4 texels each) with nrows * C <= F8_CHUNKS; the slab pitch is 16*C bytes, chosen by the wave at run time,
-// so chunk i of the row-major footprint simply lands at slab byte 16*i.  The host picks the widest shape whose
-// footprints fit (launch_fast); a wave whose footprint does not fit takes the gather path, so the choice only
-// affects speed, never the result.
+// Staging (round 2): the footprint window of a patch shape is FIXED -- F8_LPRW<LOG_PW> chunks (12 bytes = 4 texels)
+// wide, F8_SLAB / (16 * F8_LPRW) rows tall -- and so is the staging lane map: lane l serves chunk l % LPRW of row l / LPRW of
+// each pass, RPP = 64 / LPRW rows per pass.  Source address = scalar row-group base + a per-lane offset computed once,
+// slab address = a per-lane offset computed once + a scalar: a pass is one 12-byte load, the RGB -> RGBX expansion
+// (4 VALU) and one 16-byte LDS write.  (Round 1 let the footprint be any `nrows x C` area and derived row / column of
+// chunk lane + 64*pass by a multiply-shift division per pass: 72 of the wave's 422 VALU instructions were staging
+// arithmetic, now 28 -- profiles/r02_isa_histogram.txt.)  The host picks the shape whose window fits (launch_fast); a
+// wave whose footprint does not fit takes the gather path, so the choice only affects speed, never the result.
+//
+//   LOG_PW   patch     window (texels x rows)   rows per pass     slab
+//     7     128 x 4        168 x 7                  1  (42 lanes)    4704 B
+//     6      64 x 8         84 x 15                 3  (63 lanes)    5040 B
+//     5      32 x 16        40 x 31                 6  (60 lanes)    4960 B
+// (<= 5040 B per wave = 20 160 B per block: 8 blocks per CU fit the 160 KB of LDS)
 constexpr int F8_PX = 8;
-constexpr int F8_PASSES = 6;                            // staging instructions per wave
-constexpr int F8_CHUNKS = 64 * F8_PASSES;               // 384 chunks = 1536 texels = 6 KB of RGBX per wave
+constexpr int F8_SLAB = 5040;                           // bytes of LDS per wave
+template <int LOG_PW> struct F8Window {
+    static constexpr int LPRW = LOG_PW == 7 ? 42 : LOG_PW == 6 ? 21 : 10;   // chunks (staging lanes) per window row
+    static constexpr int RPP = 64 / LPRW;                                   // window rows per staging pass
+    static constexpr int LPITCH = 16 * LPRW;                                // slab bytes per window row
+    static constexpr int ROWS = F8_SLAB / LPITCH;                           // window rows
+    static constexpr int PASSES = (ROWS + RPP - 1) / RPP;
+};
+inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // host + device twin of the `staged` test
+    const int lprw = log_pw == 7 ? 42 : log_pw == 6 ? 21 : 10;
+    return nrows >= 64 / lprw && nrows <= F8_SLAB / (16 * lprw) && ((ntex + 3) >> 2) <= lprw;
+}
 
 #ifndef RWH_F8_WAVES
 #define RWH_F8_WAVES 1
+#endif
+#ifndef RWH_F8_WAVES_U8
+#define RWH_F8_WAVES_U8 8   // uint8 output: 64 VGPRs (no spills) and 20 160 B of LDS per block -> 8 waves per SIMD (+2.4 % over 6)
 #endif
 // Order of work inside a wave: the two END pixels of every lane (own reciprocals) give the footprint and the staging
 // loads go out at once; the other six pixels are computed run by run (3 + 3, one batch inversion each) right before
@@ -445,7 +467,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
     constexpr int LPR = PW / 8;                             // lanes per patch row
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
-    __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * F8_CHUNKS];
+    // float32 output: 3 KB more per wave, through which a run's pixels are re-dealt into coalesced 16-byte stores (blend_store)
+    constexpr int XPOSE = sizeof(DstT) == 1 ? 0 : 3072;
+    constexpr int SLAB = F8_SLAB + XPOSE;
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][SLAB];
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
     const unsigned b = blockIdx.x;
@@ -540,34 +565,34 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
     // footprint: rows ymn..ymx+1, texels xmn..xmx+1, as nrows x C chunks of 4 texels
+    using Win = F8Window<LOG_PW>;
     const int nrows = ymx - ymn + 2, C = (xmx - xmn + 5) >> 2;
-    const int total = nrows * C;
     // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row (a chunk may read
-    // up to 9 bytes past the footprint's last texel: never past the row below), and the footprint fits the slab
+    // up to 9 bytes past the footprint's last texel: never past the row below), and the footprint fits the window
     const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
-                        (nrows <= F8_CHUNKS) & (C <= F8_CHUNKS / 4) & (total <= F8_CHUNKS);
+                        (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
 
-    // ---- staging loads go out now: chunk i = lane + 64*p of the row-major footprint ------------------------------
+    // ---- staging loads go out now: lane -> (row srow of the pass, chunk scol), fixed for the kernel ---------------------
     unsigned char* my = slab[wave];
-    pk3 v[F8_PASSES];
+    pk3 v[Win::PASSES];
+    // lanes outside the footprint (chunk >= C, or past the last full row of a pass) load nothing: the texture-address
+    // path charges per lane (~14 B / clk / CU), and at 79 % busy it was the kernel's second bottleneck
+    const int srow = lane / Win::LPRW, scol = lane - srow * Win::LPRW;
+    const bool sactive = (srow < Win::RPP) & (scol < C);
+    const uint32_t wl = (uint32_t)(srow * Win::LPITCH + scol * 16);               // the lane's slab byte inside a pass
     if (staged) {
         const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
-        // row = i / C as (i * m) >> 16 with m = floor(2^16 / C) + 1: exact while i * (m*C - 2^16) < 2^16, and
-        // i < 384, m*C - 2^16 <= C <= 96
-        // (v_rcp_f32 is good to 1 ulp: the quotient's error, < 2^16/C * 2^-22, stays below its distance 1/C from the
-        // next integer -- or the quotient is an exact power of two -- so the floor is the exact one)
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f * __builtin_amdgcn_rcpf((float)C))) + 1u;
-        const uint32_t last = (uint32_t)total - 1u;
+        const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)scol));
 #pragma unroll
-        for (int p = 0; p < F8_PASSES; ++p) {
-            if (64 * p < total) {                                   // uniform: unused passes cost nothing
-                // lanes past the footprint's last chunk re-read it (no exec masking, nothing stored for them)
-                const uint32_t i = min((uint32_t)(lane + 64 * p), last);
-                const uint32_t row = mul24(i, m) >> 16, col = i - mul24_s(row, (uint32_t)C);   // all factors < 2^24
+        for (int p = 0; p < Win::PASSES; ++p) {
+            if (p * Win::RPP < nrows && sactive) {                      // first half uniform: unused passes cost nothing
+                // the last pass is pulled back so that it ends on the footprint's last row (it re-stages rows the pass
+                // before it already wrote: same bytes to the same place)
+                const int r0 = min(p * Win::RPP, nrows - Win::RPP);
 #ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
-                v[p] = pk3{i, i * 3u, i * 5u};
+                v[p] = pk3{goff, goff * 3u, goff * 5u};
 #else
-                __builtin_memcpy(&v[p], gbase + (size_t)mad24_s(row, pitch, mul24_12(col)), 12);
+                __builtin_memcpy(&v[p], gbase + (size_t)((uint32_t)r0 * pitch) + goff, 12);
 #endif
             }
         }
@@ -576,23 +601,24 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     uint32_t a0[FP_PX], b0[FP_PX], a1[FP_PX], b1[FP_PX];
     float wx0[FP_PX], wx1[FP_PX], wy0[FP_PX], wy1[FP_PX];
     if (staged) {
-        const uint32_t lpitch = 16u * (uint32_t)C;                                          // uniform slab pitch
+        constexpr uint32_t lpitch = Win::LPITCH;                                            // slab pitch
         // slab byte of tap (iy, ix) = (iy - ymn) * lpitch + (ix - xmn) * 4, straight from the hi dwords: the 24-bit
         // multiply sees hy & 0xFFFFFF = 0x380000 + iy, the shift drops the exponent bits of hx; both constants, the
         // footprint origin and the slab's own LDS offset go into one uniform
         // (the multiply-add is spelled in assembly: given __umul24, LLVM distributes the subtraction and emits a
         //  quarter-rate v_mul_lo_u32 per tap)
-        const uint32_t slab_off = (uint32_t)wave * (16u * F8_CHUNKS);
+        const uint32_t slab_off = (uint32_t)wave * (uint32_t)SLAB;
         const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;   // uniform
 #pragma unroll
-        for (int p = 0; p < F8_PASSES; ++p) {
-            if (64 * p < total && lane + 64 * p < total) {      // 12 packed bytes -> 4 RGBX texels
+        for (int p = 0; p < Win::PASSES; ++p) {
+            if (p * Win::RPP < nrows && sactive) {                      // 12 packed bytes -> 4 RGBX texels
+                const int r0 = min(p * Win::RPP, nrows - Win::RPP);
                 uint4 t4;
                 t4.x = v[p].a;
                 t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
                 t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
                 t4.w = v[p].c >> 8;
-                *reinterpret_cast<uint4*>(my + 16 * (lane + 64 * p)) = t4;
+                *reinterpret_cast<uint4*>(my + (uint32_t)r0 * lpitch + wl) = t4;
             }
         }
         // the slab is wave-private: order this wave's LDS writes before its LDS reads, no block barrier
@@ -617,7 +643,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
             const int first = tshift - (lcol + (PW / 2) * h);   // local pixels at columns >= first are this tile's
             if constexpr (PSTR > 1) {
                 // float32 output: re-deal through the free upper half of the slab when there is one (uniform)
-                unsigned char* xp = (total <= F8_CHUNKS / 2 && tshift == 0) ? my + 16 * (F8_CHUNKS / 2) : nullptr;
+                unsigned char* xp = tshift == 0 ? my + F8_SLAB : nullptr;
                 blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
                                         xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
             } else {
@@ -672,10 +698,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
 }
 
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? RWH_F8_WAVES_U8 : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? RWH_F8_WAVES_U8 : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
@@ -723,7 +749,7 @@ template <int LOG_PW>
 __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW, LPR = PW / 8, WX = 128 / PW;
     constexpr double MAGIC_R = MAGIC + 0.5;                 // hi(s + MAGIC_R) - MAGIC_HI = floor(s + 0.5)
-    __shared__ __attribute__((aligned(16))) unsigned char slab[4][16 * F8_CHUNKS];
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][F8_SLAB];
 
     const unsigned b = blockIdx.x;
     const unsigned logical = (b & 7u) * a.cpx + (b >> 3);
@@ -796,10 +822,10 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
     // footprint rows ymn..ymx, texels xmn..xmx (a corner within NN_TIE of a boundary may really round one further:
     // such pixels never use the slab); one row of slack below for the 9 bytes a chunk may read past its last texel
+    using Win = F8Window<LOG_PW>;
     const int nrows = ymx - ymn + 1, C = (xmx - xmn + 4) >> 2;
-    const int total = nrows * C;
     const bool staged = wpos & (xmn >= 0) & (xmx <= a.bound_w - 1) & (ymn >= 0) & (ymx <= min(a.bound_h - 1, a.src_h - 2)) &
-                        (nrows <= F8_CHUNKS) & (C <= F8_CHUNKS / 4) & (total <= F8_CHUNKS);
+                        (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
 
     if (!staged) {                                          // every pixel by the reference's formula
 #pragma unroll
@@ -813,37 +839,40 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
         return;
     }
 
-    pk3 v[F8_PASSES];
+    // staging: the fixed lane map of warp_rgb8_fast8 (see F8Window)
+    pk3 v[Win::PASSES];
+    const int sl = min(lane, Win::RPP * Win::LPRW - 1);
+    const int srow = sl / Win::LPRW, scol = sl - srow * Win::LPRW;
+    const uint32_t wl = (uint32_t)(srow * Win::LPITCH + scol * 16);
     {
         const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)(65536.0f * __builtin_amdgcn_rcpf((float)C))) + 1u;
-        const uint32_t last = (uint32_t)total - 1u;
+        const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)min(scol, C - 1)));
 #pragma unroll
-        for (int p = 0; p < F8_PASSES; ++p) {
-            if (64 * p < total) {
-                const uint32_t i = min((uint32_t)(lane + 64 * p), last);
-                const uint32_t row = mul24(i, m) >> 16, col = i - mul24_s(row, (uint32_t)C);
-                __builtin_memcpy(&v[p], gbase + (size_t)mad24_s(row, pitch, mul24_12(col)), 12);
+        for (int p = 0; p < Win::PASSES; ++p) {
+            if (p * Win::RPP < nrows) {
+                const int r0 = min(p * Win::RPP, nrows - Win::RPP);
+                __builtin_memcpy(&v[p], gbase + (size_t)((uint32_t)r0 * pitch) + goff, 12);
             }
         }
     }
     unsigned char* my = slab[wave];
+    constexpr uint32_t lpitch = Win::LPITCH;
 #pragma unroll
-    for (int p = 0; p < F8_PASSES; ++p) {
-        if (64 * p < total && lane + 64 * p < total) {
+    for (int p = 0; p < Win::PASSES; ++p) {
+        if (p * Win::RPP < nrows) {
+            const int r0 = min(p * Win::RPP, nrows - Win::RPP);
             uint4 t4;
             t4.x = v[p].a;
             t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
             t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
             t4.w = v[p].c >> 8;
-            *reinterpret_cast<uint4*>(my + 16 * (lane + 64 * p)) = t4;
+            *reinterpret_cast<uint4*>(my + (uint32_t)r0 * lpitch + wl) = t4;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t lpitch = 16u * (uint32_t)C;
-    const uint32_t slab_off = (uint32_t)wave * (16u * F8_CHUNKS);
+    const uint32_t slab_off = (uint32_t)wave * (uint32_t)F8_SLAB;
     const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -874,10 +903,11 @@ __global__ __launch_bounds__(256) void warp_rgb8_nn(const FastArgs a) { nn_body<
 template <int LOG_PW>
 __global__ __launch_bounds__(256) void warp_rgb8_nn_tab(const FastArgs a, const CoefTab t) { nn_body<LOG_PW>(a, t.e); }
 
-// Source footprint of a pw x ph output patch whose top-left pixel is (row r, column c) of the output grid: chunks (12 B =
-// 4 texels, what the slab has to hold) and an estimate of the 128-byte lines its staging loads touch.  Host-side twin
-// of the kernel's footprint arithmetic, used only to choose the patch shape.  false: W <= 0 at a corner.
-inline bool patch_footprint(const FastArgs& a, double r, double c, int pw, int ph, long long* chunks, double* lines) {
+// Source footprint of a pw x ph output patch whose top-left pixel is (row r, column c) of the output grid: its rows and
+// texels (what the shape's staging window has to hold, f8_window_fits) and an estimate of the 128-byte lines its staging
+// loads touch.  Host-side twin of the kernel's footprint arithmetic, used only to choose the patch shape.
+// false: W <= 0 at a corner.
+inline bool patch_footprint(const FastArgs& a, double r, double c, int pw, int ph, long long* rows, long long* texels, double* lines) {
     double xmin = 1e300, xmax = -1e300, ymin = 1e300, ymax = -1e300;
     for (int k = 0; k < 4; ++k) {
         const double rr = r + (k & 2 ? ph - 1 : 0), cc = c + (k & 1 ? pw - 1 : 0);   // rows of the whole output grid
@@ -888,9 +918,8 @@ inline bool patch_footprint(const FastArgs& a, double r, double c, int pw, int p
         xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax; ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
     }
     if (!(xmax - xmin < 1e6 && ymax - ymin < 1e6)) return false;
-    const long long nrows = (long long)(ymax - ymin) + 2, ntex = (long long)(xmax - xmin) + 2;
-    *chunks = nrows * ((ntex + 3) >> 2);
-    *lines = (double)nrows * (3.0 * (double)ntex / 128.0 + 1.0);
+    *rows = (long long)(ymax - ymin) + 2; *texels = (long long)(xmax - xmin) + 2;
+    *lines = (double)*rows * (3.0 * (double)*texels / 128.0 + 1.0);
     return true;
 }
 

@@ -81,6 +81,22 @@ def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=Tru
     return out[0] if squeeze else out
 
 
+def warp_plan(src_shape, src_dtype, inv_h, grid, bound_hw, interp, out_dtype, rows=None, exact=False):
+    """Name of the kernel `warp_backward` launches for this configuration (rwh_warp_plan: the library's own dispatch,
+    nothing is launched and no GPU is needed).  src_shape: (B, H, W, C) or (H, W, C)."""
+    lib = _lib.load()
+    B, H, W, C = (1,) + tuple(src_shape) if len(src_shape) == 3 else tuple(src_shape)
+    ih = np.ascontiguousarray(inv_h, dtype=np.float64)
+    n_h = 1 if ih.size == 9 else ih.size // 9
+    r0, r1 = (0, grid.out_h) if rows is None else rows
+    buf = ctypes.create_string_buffer(128)
+    check(lib.rwh_warp_plan(H, W, C, _DTYPE[src_dtype], B, ih.reshape(-1).ctypes.data_as(ctypes.POINTER(ctypes.c_double)), n_h,
+                            grid.x0, grid.step_x, grid.x_last, grid.y0, grid.step_y, grid.y_last, grid.out_h, grid.out_w,
+                            int(bound_hw[0]), int(bound_hw[1]), INTERP[interp], _DTYPE[out_dtype], r0, r1,
+                            RWH_WARP_EXACT if exact else 0, buf, 128), "rwh_warp_plan")
+    return buf.value.decode()
+
+
 def dlt4_batched(pts_a, pts_b, idx):
     """Launch K1.  pts_*: [M,2] float32, idx: [K,4] int32 -> (H [K,9] float32, flags [K] uint8)."""
     lib = _lib.load()
