@@ -80,6 +80,11 @@ RWH_API int rwh_lab_tune(int knob, int value);
  * homography.py:208).  bound_w/bound_h are clipped to the source size.
  * Bilinear weights come from the float64 fraction; the blend itself runs in
  * float32 (tolerance vs the float64 reference: 1e-4 relative, typ. 3e-7).
+ * Mask edge, fast kernels (no RWH_WARP_EXACT): source coordinates are rounded once onto a 2^-32 px grid before the bounds
+ * test, so a coordinate inside (-2^-33, 0) or (bound-1, bound-1 + 2^-33) counts as ON the edge texel where the reference
+ * (which tests the unrounded float64, homography.py:131) returns 0.  On a generic map that is one pixel in ~10^9; an
+ * axis-aligned map whose inv(H) carries 1e-16 round-off (a rotation by numpy's pi) can put a whole border row or column
+ * there.  RWH_WARP_EXACT reproduces the reference's decision bit for bit (tests: test_warp_image_edge_band_vs_oracle).
  *
  * Only rows [row_begin, row_end) are produced; d_dst points at row `row_begin`
  * of image 0 and image b at d_dst + b*dst_image_stride (bytes).  This is the
@@ -99,6 +104,21 @@ RWH_API int rwh_warp_backward(const void* d_src, int src_h, int src_w, int chann
                       int out_h, int out_w, int bound_h, int bound_w, int interp,
                       void* d_dst, int dst_dtype, int64_t dst_image_stride,
                       int row_begin, int row_end, unsigned flags, void* stream);
+
+/*
+ * The interpolators on coordinates the caller computed: replaces convertfunc[convert](z_t, img, h, w, mh, mw), i.e.
+ *   nearestNeighbor  homography.py:108-121   (z + 0.5 truncated to int32, mask on the integers, gather)
+ *   bilinear         homography.py:123-138   (mask on the float64 coordinates, truncation, float64 lerps)
+ * d_x / d_y: the n source coordinates (rows 0 and 1 of the reference's dehomogenised 3 x N z_t), float64, on the device;
+ * d_out: n x channels, element type = the image's for RWH_NEAREST (dst_dtype == src_dtype), float64 for RWH_BILINEAR
+ * (dst_dtype RWH_F64) -- the reference's float64 arithmetic operation by operation, bit-identical to numpy's;
+ * (bound_h, bound_w): the `h, w` arguments of the reference's call (clipped to the image); flags: RWH_WARP_ZERO_ORIGIN
+ * blanks texel (0,0) of the image first, as both interpolators do to the caller's array.  The +1 taps are clamped to the
+ * image where the reference raises IndexError (their weight is 0 there).
+ */
+RWH_API int rwh_sample_points(const void* d_img, int src_h, int src_w, int channels, int src_dtype,
+                      const double* d_x, const double* d_y, int64_t n, int bound_h, int bound_w, int interp,
+                      void* d_out, int dst_dtype, unsigned flags, void* stream);
 
 /*
  * Which kernel rwh_warp_backward would launch for these arguments (same dispatch code, nothing is launched, no device
@@ -161,6 +181,14 @@ RWH_API int rwh_score_count(const float* d_h, const float* d_pts_a, const float*
  */
 RWH_API int rwh_project_points(const float* d_h, const float* d_pts, int m, int inverse,
                        float* d_out, void* stream);
+
+/*
+ * General form of the same two methods: d_h 9 elements, d_pts3 3 x M (rows x, y, w: the caller's third row, which a 3 x M
+ * input keeps, ransac.py:58-62), d_out 3 x M, all float32 (dtype RWH_F32) or all float64 (RWH_F64: what numpy computes when
+ * model.val -- the float64 refit after RANSAC.run -- or the points are float64).  For reproj the caller passes inv(val)
+ * (numpy.linalg.inv on the host, as ransac.py:74 does).  Same k-order: rounded multiply, FMA, FMA; IEEE divides.
+ */
+RWH_API int rwh_project_points_ex(const void* d_h, const void* d_pts3, int m, int dtype, void* d_out, void* stream);
 
 /*
  * The RANSAC search of ransac.py:176-202 as ONE call: (optional) reset of the two packed keys, then

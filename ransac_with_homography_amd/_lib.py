@@ -20,8 +20,8 @@ RWH_BATCH_DEVICE_SAMPLING = 1
 RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW = 0, 1
 
 # every symbol include/rwh.h declares (tests check the library exports them all)
-EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_warp_backward", "rwh_warp_plan", "rwh_dlt4_batched",
-           "rwh_score_count", "rwh_project_points", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama")
+EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
+           "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama")
 
 
 class RwhUnavailable(RuntimeError):
@@ -53,6 +53,8 @@ def _bind(lib):
     lib.rwh_warp_plan.restype = i32
     lib.rwh_warp_plan.argtypes = [i32, i32, i32, i32, i32, c.POINTER(f64), i32, f64, f64, f64, f64, f64, f64,
                                   i32, i32, i32, i32, i32, i32, i32, i32, u32, c.c_char_p, i32]
+    lib.rwh_sample_points.restype = i32
+    lib.rwh_sample_points.argtypes = [vp, i32, i32, i32, i32, vp, vp, i64, i32, i32, i32, vp, i32, u32, vp]
     lib.rwh_dlt4_batched.restype = i32
     lib.rwh_dlt4_batched.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     lib.rwh_score_count.restype = i32
@@ -64,6 +66,8 @@ def _bind(lib):
     lib.rwh_stitch_panorama.restype = i32
     lib.rwh_stitch_panorama.argtypes = [vp, i32, i32, vp, i32, i32, c.POINTER(f64), i32, i32, i32, i32,
                                         i32, i32, i32, i32, i32, i32, i32, f64, vp, u32, vp]
+    lib.rwh_project_points_ex.restype = i32
+    lib.rwh_project_points_ex.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.rwh_project_points.restype = i32
     lib.rwh_project_points.argtypes = [vp, vp, i32, i32, vp, vp]
     return lib

@@ -422,7 +422,41 @@ __global__ __launch_bounds__(256) void project_kernel(const float* __restrict__ 
     out[j] = px; out[m + j] = py; out[2 * (size_t)m + j] = pw;
 }
 
+// General form of HomoModel.fwd / reproj (ransac.py:55-76): val @ x for a 3 x M x whose third row is the caller's (not
+// necessarily 1), in float32 or float64 -- numpy promotes val @ x to float64 when either operand is (model.val is the
+// float64 refit after RANSAC.run).  OpenBLAS k-order for both types: rounded multiply, FMA, FMA (checked against numpy
+// with exact rational arithmetic); then y / (y[2] + 1e-10) with IEEE divides.
+template <typename T>
+__global__ __launch_bounds__(256) void project3_kernel(const T* __restrict__ h, const T* __restrict__ pts3, int m, T* __restrict__ out) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= m) return;
+    const T x = pts3[j], y = pts3[m + j], w = pts3[2 * (size_t)m + j];
+    T a[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        T acc = h[3 * r] * x;
+        acc = fma(h[3 * r + 1], y, acc);
+        a[r] = fma(h[3 * r + 2], w, acc);
+    }
+    const T den = a[2] + (T)1e-10;
+    out[j] = a[0] / den; out[m + j] = a[1] / den; out[2 * (size_t)m + j] = a[2] / den;
+}
+
 }  // namespace rwh
+
+extern "C" int rwh_project_points_ex(const void* d_h, const void* d_pts3, int m, int dtype, void* d_out, void* stream) {
+    using namespace rwh;
+    if (!d_h || !d_pts3 || !d_out || m <= 0) return RWH_E_INVALID;
+    if (dtype != RWH_F32 && dtype != RWH_F64) return RWH_E_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (dtype == RWH_F32)
+        hipLaunchKernelGGL(project3_kernel<float>, dim3((m + 255) / 256), dim3(256), 0, s, static_cast<const float*>(d_h),
+                           static_cast<const float*>(d_pts3), m, static_cast<float*>(d_out));
+    else
+        hipLaunchKernelGGL(project3_kernel<double>, dim3((m + 255) / 256), dim3(256), 0, s, static_cast<const double*>(d_h),
+                           static_cast<const double*>(d_pts3), m, static_cast<double*>(d_out));
+    return check_launch();
+}
 
 extern "C" int rwh_project_points(const float* d_h, const float* d_pts, int m, int inverse, float* d_out, void* stream) {
     using namespace rwh;

@@ -237,6 +237,65 @@ __device__ __forceinline__ void load_texel_f64(const unsigned char* img, size_t 
     }
 }
 
+// One sample at the float64 source coordinate (sx, sy), the reference's arithmetic operation by operation (see above).
+template <typename SrcT, int C, typename DstT, int INTERP>
+__device__ __forceinline__ void sample_exact(const unsigned char* simg, size_t img_bytes, int src_h, int src_w, int bound_h, int bound_w,
+                                             double sx, double sy, DstT* out) {
+    if constexpr (INTERP == RWH_NEAREST) {
+        const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
+        const bool valid = (xi >= 0) & (xi <= bound_w - 1) & (yi >= 0) & (yi <= bound_h - 1);
+        if (valid) {
+            const size_t off = ((size_t)yi * (size_t)src_w + (size_t)xi) * (size_t)(C * sizeof(SrcT));
+            const SrcT* p = reinterpret_cast<const SrcT*>(simg + off);
+#pragma unroll
+            for (int k = 0; k < C; ++k) out[k] = (DstT)p[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) out[k] = (DstT)0;
+        }
+    } else {
+        double o[C];
+        const double bw1 = (double)(bound_w - 1), bh1 = (double)(bound_h - 1);
+        const bool valid = (sx >= 0.0) & (sx <= bw1) & (sy >= 0.0) & (sy <= bh1);
+        if (valid) {
+            const int ix = (int)sx, iy = (int)sy;
+            const double fx = sx - (double)ix, fy = sy - (double)iy;
+            const double gx = 1.0 - fx, gy = 1.0 - fy;
+            const int ix1 = min(ix + 1, src_w - 1), iy1 = min(iy + 1, src_h - 1);
+            double p00[C], p01[C], p10[C], p11[C];
+            load_texel_f64<SrcT, C>(simg, img_bytes, src_w, iy, ix, p00);
+            load_texel_f64<SrcT, C>(simg, img_bytes, src_w, iy, ix1, p01);
+            load_texel_f64<SrcT, C>(simg, img_bytes, src_w, iy1, ix, p10);
+            load_texel_f64<SrcT, C>(simg, img_bytes, src_w, iy1, ix1, p11);
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+                const double top = p00[k] * gx + p01[k] * fx;   // contraction is off: three roundings, like numpy
+                const double bot = p10[k] * gx + p11[k] * fx;
+                o[k] = top * gy + bot * fy;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < C; ++k) o[k] = 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < C; ++k) {
+            if constexpr (sizeof(DstT) == 1) out[k] = (unsigned char)(int)o[k];
+            else out[k] = (DstT)o[k];
+        }
+    }
+}
+
+// convertfunc[...](z_t, img, h, w, mh, mw) on coordinates the caller computed (homography.py:108-138): one thread per point.
+template <typename SrcT, int C, typename DstT, int INTERP>
+__global__ __launch_bounds__(256) void sample_points_kernel(const unsigned char* img, int src_h, int src_w, int bound_h, int bound_w,
+                                                            const double* __restrict__ xs, const double* __restrict__ ys, long long n,
+                                                            DstT* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t img_bytes = (size_t)src_h * (size_t)src_w * (size_t)(C * sizeof(SrcT));
+    sample_exact<SrcT, C, DstT, INTERP>(img, img_bytes, src_h, src_w, bound_h, bound_w, xs[i], ys[i], out + i * C);
+}
+
 template <typename SrcT, int C, typename DstT, int INTERP>
 __global__ __launch_bounds__(256) void warp_exact(const WarpArgs a) {
     unsigned tx, ty, img;
@@ -252,7 +311,6 @@ __global__ __launch_bounds__(256) void warp_exact(const WarpArgs a) {
     DstT* drow = reinterpret_cast<DstT*>(a.dst + (long long)img * a.dst_img_stride) +
                  ((size_t)rr * (size_t)a.out_w + (size_t)c0) * C;
     const double y = grid_coord(r, a.out_h, a.y0, a.step_y, a.y_last);
-    const double bw1 = (double)(a.bound_w - 1), bh1 = (double)(a.bound_h - 1);
 #pragma unroll
     for (int j = 0; j < PX; ++j) {
         const int c = c0 + j;
@@ -262,47 +320,7 @@ __global__ __launch_bounds__(256) void warp_exact(const WarpArgs a) {
         const double Y = fma(a.ih[4], y, a.ih[3] * x) + a.ih[5];
         const double W = fma(a.ih[7], y, a.ih[6] * x) + a.ih[8];
         const double sx = X / W, sy = Y / W;
-        if constexpr (INTERP == RWH_NEAREST) {
-            const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
-            const bool valid = (xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1);
-            if (valid) {
-                const size_t off = ((size_t)yi * (size_t)a.src_w + (size_t)xi) * (size_t)(C * sizeof(SrcT));
-                const SrcT* p = reinterpret_cast<const SrcT*>(simg + off);
-#pragma unroll
-                for (int k = 0; k < C; ++k) drow[j * C + k] = (DstT)p[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < C; ++k) drow[j * C + k] = (DstT)0;
-            }
-        } else {
-            double o[C];
-            const bool valid = (sx >= 0.0) & (sx <= bw1) & (sy >= 0.0) & (sy <= bh1);
-            if (valid) {
-                const int ix = (int)sx, iy = (int)sy;
-                const double fx = sx - (double)ix, fy = sy - (double)iy;
-                const double gx = 1.0 - fx, gy = 1.0 - fy;
-                const int ix1 = min(ix + 1, a.src_w - 1), iy1 = min(iy + 1, a.src_h - 1);
-                double p00[C], p01[C], p10[C], p11[C];
-                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy, ix, p00);
-                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy, ix1, p01);
-                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix, p10);
-                load_texel_f64<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix1, p11);
-#pragma unroll
-                for (int k = 0; k < C; ++k) {
-                    const double top = p00[k] * gx + p01[k] * fx;   // contraction is off: three roundings, like numpy
-                    const double bot = p10[k] * gx + p11[k] * fx;
-                    o[k] = top * gy + bot * fy;
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < C; ++k) o[k] = 0.0;
-            }
-#pragma unroll
-            for (int k = 0; k < C; ++k) {
-                if constexpr (sizeof(DstT) == 1) drow[j * C + k] = (unsigned char)(int)o[k];
-                else drow[j * C + k] = (DstT)o[k];
-            }
-        }
+        sample_exact<SrcT, C, DstT, INTERP>(simg, img_bytes, a.src_h, a.src_w, a.bound_h, a.bound_w, sx, sy, drow + j * C);
     }
 }
 
@@ -608,4 +626,48 @@ extern "C" int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, 
                                      row_end, flags, nullptr);
     rwh::g_plan_buf = nullptr; rwh::g_plan_len = 0;
     return st;
+}
+
+namespace rwh {
+template <typename SrcT, int C>
+static int sample_dispatch(const unsigned char* img, int src_h, int src_w, int bound_h, int bound_w, const double* xs, const double* ys,
+                           long long n, int interp, void* out, int dst_dtype, hipStream_t s) {
+    const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    if (interp == RWH_NEAREST) {
+        if (dst_dtype != elem<SrcT>::dtype) return RWH_E_UNSUPPORTED;
+        hipLaunchKernelGGL((sample_points_kernel<SrcT, C, SrcT, RWH_NEAREST>), grid, block, 0, s, img, src_h, src_w, bound_h, bound_w, xs, ys, n,
+                           static_cast<SrcT*>(out));
+    } else if (dst_dtype == RWH_F64) {
+        hipLaunchKernelGGL((sample_points_kernel<SrcT, C, double, RWH_BILINEAR>), grid, block, 0, s, img, src_h, src_w, bound_h, bound_w, xs, ys, n,
+                           static_cast<double*>(out));
+    } else {
+        return RWH_E_UNSUPPORTED;
+    }
+    return check_launch();
+}
+}  // namespace rwh
+
+extern "C" int rwh_sample_points(const void* d_img, int src_h, int src_w, int channels, int src_dtype, const double* d_x, const double* d_y,
+                                 int64_t n, int bound_h, int bound_w, int interp, void* d_out, int dst_dtype, unsigned flags, void* stream) {
+    using namespace rwh;
+    if (!d_img || !d_x || !d_y || !d_out || n < 0 || src_h < 1 || src_w < 1 || bound_h <= 0 || bound_w <= 0) return RWH_E_INVALID;
+    if (interp != RWH_NEAREST && interp != RWH_BILINEAR) return RWH_E_INVALID;
+    if (channels != 3 && channels != 4) return RWH_E_UNSUPPORTED;
+    if (src_dtype != RWH_U8 && src_dtype != RWH_F32) return RWH_E_UNSUPPORTED;
+    if (n == 0) return RWH_OK;
+    if (n > (1ll << 31) * 255) return RWH_E_UNSUPPORTED;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t esz = src_dtype == RWH_U8 ? 1 : 4;
+    if (flags & RWH_WARP_ZERO_ORIGIN) {
+        hipLaunchKernelGGL(zero_origin_kernel, dim3(1), dim3(64), 0, s, const_cast<unsigned char*>(static_cast<const unsigned char*>(d_img)),
+                           0ll, 1, (int)(channels * esz));
+        if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
+    }
+    const unsigned char* img = static_cast<const unsigned char*>(d_img);
+    const int bh = bound_h < src_h ? bound_h : src_h, bw = bound_w < src_w ? bound_w : src_w;
+    if (src_dtype == RWH_U8)
+        return channels == 3 ? sample_dispatch<unsigned char, 3>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s)
+                             : sample_dispatch<unsigned char, 4>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s);
+    return channels == 3 ? sample_dispatch<float, 3>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s)
+                         : sample_dispatch<float, 4>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s);
 }

@@ -698,10 +698,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
 }
 
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? RWH_F8_WAVES_U8 : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? RWH_F8_WAVES_U8 : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.

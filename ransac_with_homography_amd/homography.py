@@ -233,15 +233,41 @@ def wrapPerspectiveScan(img, H, res, convert='nn'):
 perspectiveTransform = wrapPerspective  # name used by BASELINE.json's north_star
 
 
+def _sample(z_t, img, h, w, mh, mw, convert):
+    """Common body of the two interpolators on caller-computed coordinates: `rwh_sample_points` (the reference's float64
+    arithmetic, bit-identical results).  Like the reference it blanks texel (0,0) of the caller's image and, for
+    'bilinear', writes 0 into the masked columns of the caller's z_t (homography.py:131-132: `z_t = z_t.T` is a view)."""
+    import torch
+    dev = _lib.require_gpu()
+    chn = img.shape[2]
+    if _is_tensor(z_t):
+        zx, zy = z_t[0].to(dev, torch.float64).contiguous(), z_t[1].to(dev, torch.float64).contiguous()
+    else:
+        z_t = np.asarray(z_t)
+        zx = torch.from_numpy(np.ascontiguousarray(z_t[0], dtype=np.float64)).to(dev)
+        zy = torch.from_numpy(np.ascontiguousarray(z_t[1], dtype=np.float64)).to(dev)
+    src, was_numpy, np_dtype = _to_device(img)
+    out = kernels.sample_points(src, zx, zy, (h, w), convert, zero_origin=True).reshape(mh, mw, chn)
+    if convert == 'bilinear' and not _is_tensor(z_t) and z_t.dtype.kind == 'f':
+        mask = (z_t[0] > w - 1) | (z_t[0] < 0) | (z_t[1] > h - 1) | (z_t[1] < 0)
+        z_t[0:2, mask] = 0
+    if not was_numpy:
+        return out
+    _blank_origin(img)
+    res = out.cpu().numpy()
+    return res if (convert == 'bilinear' or res.dtype == np_dtype) else res.astype(np_dtype)
+
+
 def nearestNeighbor(z_t, img, h, w, mh, mw):
-    """Interpolator entry of `convertfunc` (homography.py:108-121) is fused into the warp
-    kernel; it cannot be fed precomputed coordinates."""
-    raise NotImplementedError("fused into rwh_warp_backward: call wrapPerspective(..., convert='nn')")
+    """homography.py:108-121 on caller-computed coordinates z_t (3 x N, dehomogenised): (z_t + 0.5) truncated to int32,
+    mask on the integers, gather; returns mh x mw x C in the image's dtype."""
+    return _sample(z_t, img, h, w, mh, mw, 'nn')
 
 
 def bilinear(z_t, img, h, w, mh, mw):
-    """See nearestNeighbor (homography.py:123-138)."""
-    raise NotImplementedError("fused into rwh_warp_backward: call wrapPerspective(..., convert='bilinear')")
+    """homography.py:123-138 on caller-computed coordinates: mask on the float64 coordinates, truncation, float64 lerps;
+    returns mh x mw x C float64."""
+    return _sample(z_t, img, h, w, mh, mw, 'bilinear')
 
 
 convertfunc = {'nn': nearestNeighbor, 'bilinear': bilinear}

@@ -81,6 +81,22 @@ def warp_backward(src, inv_h, grid, bound_hw, interp, out_dtype, zero_origin=Tru
     return out[0] if squeeze else out
 
 
+def sample_points(img, xs, ys, bound_hw, interp, zero_origin=True):
+    """Launch the interpolator on precomputed coordinates (rwh_sample_points): img [H,W,C] uint8|float32 GPU tensor, xs / ys
+    [N] float64 GPU tensors -> [N, C] (image dtype for 'nn', float64 for 'bilinear')."""
+    lib = _lib.load()
+    _dev_check(img, xs, ys)
+    assert xs.dtype == torch.float64 and ys.dtype == torch.float64 and xs.numel() == ys.numel()
+    H, W, C = img.shape
+    n = xs.numel()
+    out_dtype = img.dtype if interp == "nn" else torch.float64
+    out = torch.empty((n, C), dtype=out_dtype, device=img.device)
+    check(lib.rwh_sample_points(_ptr(img), H, W, C, _DTYPE[img.dtype], _ptr(xs), _ptr(ys), n, int(bound_hw[0]), int(bound_hw[1]),
+                                INTERP[interp], _ptr(out), _DTYPE[out_dtype], RWH_WARP_ZERO_ORIGIN if zero_origin else 0,
+                                _lib.stream_ptr()), "rwh_sample_points")
+    return out
+
+
 def warp_plan(src_shape, src_dtype, inv_h, grid, bound_hw, interp, out_dtype, rows=None, exact=False):
     """Name of the kernel `warp_backward` launches for this configuration (rwh_warp_plan: the library's own dispatch,
     nothing is launched and no GPU is needed).  src_shape: (B, H, W, C) or (H, W, C)."""
@@ -205,6 +221,17 @@ def project_points(h9, pts, inverse):
     out = torch.empty((3, M), dtype=torch.float32, device=pts.device)
     check(lib.rwh_project_points(_ptr(h9), _ptr(pts), M, 1 if inverse else 0, _ptr(out), _lib.stream_ptr()),
           "rwh_project_points")
+    return out
+
+
+def project_points_ex(h9, pts3):
+    """General projection (rwh_project_points_ex): h9 [9], pts3 [3,M], both float32 or both float64 -> [3,M] same dtype."""
+    lib = _lib.load()
+    _dev_check(h9, pts3)
+    assert h9.dtype == pts3.dtype and h9.dtype in (torch.float32, torch.float64) and pts3.shape[0] == 3
+    out = torch.empty_like(pts3)
+    check(lib.rwh_project_points_ex(_ptr(h9), _ptr(pts3), pts3.shape[1], _DTYPE[h9.dtype], _ptr(out), _lib.stream_ptr()),
+          "rwh_project_points_ex")
     return out
 
 

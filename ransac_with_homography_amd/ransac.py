@@ -172,16 +172,36 @@ class HomoModel(Model):
 
     # -- projection helpers: one launch of the projection kernel each -------------------------
     def _project(self, P, inverse):
+        """ransac.py:55-76 with numpy's dtype rules: a 2-row input becomes a float32 3 x M with ones (ransac.py:59-60), a
+        3-row input is used as it is (third row included); `val @ x` is float32 only if both operands are, float64
+        otherwise; reproj goes through numpy.linalg.inv(val) in val's dtype (host, 3 x 3)."""
         import torch
+        P = np.asarray(P)
         nrow, m = P.shape
         assert nrow in [2, 3], "invalid input dimension for row numbers"
         dev = _lib.require_gpu()
-        h9 = torch.from_numpy(np.ascontiguousarray(self.val, dtype=np.float32).reshape(9)).to(dev)
-        pts = torch.from_numpy(_points_rows(P)).to(dev)
-        return kernels.project_points(h9, pts, inverse).cpu().numpy()
+        val = np.asarray(self.val)
+        if nrow == 2:
+            x = np.ones((3, m), dtype=np.float32)
+            x[:2, :] = P
+        else:
+            x = P
+        if val.dtype == np.float32 and x.dtype == np.float32 and nrow == 2:
+            # the RANSAC loop's own case: float32 H, w == 1, inverse by the kernel's float64 LU (bit-identical to numpy's)
+            h9 = torch.from_numpy(np.ascontiguousarray(val).reshape(9)).to(dev)
+            pts = torch.from_numpy(np.ascontiguousarray(x[:2].T)).to(dev)
+            return kernels.project_points(h9, pts, inverse).cpu().numpy()
+        if inverse:
+            val = np.linalg.inv(val)                      # ransac.py:74: float64 inside, result in val's dtype
+        dt = np.result_type(val.dtype, x.dtype)
+        if dt not in (np.float32, np.float64):
+            dt = np.dtype(np.float64)
+        h9 = torch.from_numpy(np.ascontiguousarray(val, dtype=dt).reshape(9)).to(dev)
+        pts3 = torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).to(dev)
+        return kernels.project_points_ex(h9, pts3).cpu().numpy()
 
     def fwd(self, X):
-        """val @ [X;1] / (row2 + 1e-10), float32 3 x M (ransac.py:55-64)."""
+        """val @ [X;1] / (row2 + 1e-10), 3 x M in numpy's result dtype (ransac.py:55-64)."""
         return self._project(X, False)
 
     def reproj(self, Y):
@@ -199,6 +219,17 @@ class HomoModel(Model):
         import torch
         if method not in _lib.RWH_LOSS:
             exit("Invalid method!")  # ransac.py:97
+        if np.asarray(self.val).dtype != np.float32 or np.asarray(X).dtype != np.float32 or np.asarray(Y).dtype != np.float32 \
+                or X.shape[0] != 2 or Y.shape[0] != 2:
+            # not the RANSAC loop's float32 case (e.g. model.val is the float64 refit after run()): numpy computes these in
+            # float64 -- the reference's own composition of fwd / reproj / dist (ransac.py:84-96), projections on the GPU
+            err = None
+            if method in ("fwd", "reproj"):
+                err = self.dist(self.fwd(X)[:2, :], Y)
+            if method in ("backward", "reproj"):
+                back = self.dist(self.reproj(Y)[:2, :], X)
+                err = back if err is None else err + back
+            return err
         dev = _lib.require_gpu()
         h9 = torch.from_numpy(np.ascontiguousarray(self.val, dtype=np.float32).reshape(1, 9)).to(dev)
         pa = torch.from_numpy(_points_rows(X)).to(dev)

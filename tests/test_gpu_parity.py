@@ -658,6 +658,72 @@ def test_model_helpers_match_oracle(gpu, matches):
     np.testing.assert_allclose(got, z["H"][1].reshape(3, 3), rtol=1e-6)
 
 
+def test_model_helpers_float64_and_three_row_inputs(gpu, matches):
+    """After RANSAC.run model.val is the float64 refit: fwd / reproj / computeLoss then run in float64 in the reference
+    (numpy promotes val @ x), and a 3 x M input keeps its own third row (ransac.py:58-62).  Bit-identical to the oracle."""
+    import ransac as rs
+    from oracle import rwh_oracle as orc
+    z = load_golden("g4_ransac_runs")
+    ptsA, ptsB = matches
+    X, Y = ptsA.T, ptsB.T
+    model = rs.HomoModel(th=5, d=70, n=4)
+    model.val = z["g4_s0_th5_d70_k1000_fwd_H"].copy()                   # float64 3 x 3
+    for P in (X, Y):
+        got = model.fwd(P)
+        ref = orc.project_fwd(model.val, P)
+        assert got.dtype == ref.dtype == np.float64 and np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+        got = model.reproj(P)
+        ref = orc.project_back(model.val, P)
+        assert np.array_equal(got.view(np.uint64), ref.view(np.uint64))
+    for m in ("fwd", "backward", "reproj"):
+        got, ref = model.computeLoss(X, Y, m), orc.compute_loss(model.val, X, Y, m)
+        assert got.dtype == ref.dtype and np.array_equal(got.view(np.uint64), ref.view(np.uint64)), m
+    rng = np.random.default_rng(4)
+    X3 = np.vstack([X.astype(np.float64), rng.uniform(0.5, 2.0, (1, X.shape[1]))])          # float64, third row != 1
+    X3f = X3.astype(np.float32)
+    g2 = load_golden("g2_hyp_seed0")
+    val32 = g2["H"][int(g2["winner"])].reshape(3, 3).copy()
+    for val in (model.val, val32):
+        for P in (X3, X3f):
+            model.val = val
+            for fn, ofn in ((model.fwd, orc.project_fwd), (model.reproj, orc.project_back)):
+                got, ref = fn(P), ofn(val, P)
+                assert got.dtype == ref.dtype, (val.dtype, P.dtype)
+                assert np.array_equal(got.view(np.uint8), ref.view(np.uint8)), (val.dtype, P.dtype, fn.__name__)
+
+
+@pytest.mark.parametrize("chn", [3, 4])
+def test_convertfunc_on_precomputed_coordinates(gpu, chn):
+    """homography.convertfunc['nn' | 'bilinear'](z_t, img, h, w, mh, mw) (homography.py:108-140) on coordinates the caller
+    computed -- including out-of-range ones, exact integers, .5 ties and the image's last row / column -- equals the
+    oracle's interpolators bit for bit, blanks texel (0,0) of the caller's image and (bilinear) zeroes the masked columns of
+    the caller's z_t like the reference's in-place view does."""
+    import homography as hg
+    from oracle import rwh_oracle as orc
+    rng = np.random.default_rng(5)
+    h, w, mh, mw = 37, 53, 30, 40
+    img8 = rng.integers(1, 256, (h, w, chn), dtype=np.uint8)
+    imgf = (rng.random((h, w, chn)) * 255).astype(np.float32)
+    n = mh * mw
+    z = np.ones((3, n))
+    z[0] = rng.uniform(-3, w + 2, n); z[1] = rng.uniform(-3, h + 2, n)
+    z[0][(z[0] > w - 2) & (z[0] <= w - 1)] -= 1.0; z[1][(z[1] > h - 2) & (z[1] <= h - 1)] -= 1.0   # nn ties to the last index are fine, bilinear +1 taps are not
+    z[0, :40] = np.arange(40) * 1.0; z[1, :40] = (np.arange(40) % (h - 1)) * 1.0      # exact integers (not the last row: IndexError in the reference)
+    z[0, 40:80] = np.arange(40) + 0.5; z[1, 40:80] = (np.arange(40) % (h - 1)) + 0.5  # nearest-neighbour ties
+    z[0, 80:90] = w - 1 - 1e-9; z[1, 90:100] = h - 1 - 1e-9                            # just inside the last column / row
+    z[0, 100:105] = -1e-12; z[1, 105:110] = h - 1 + 1e-12                             # just outside
+    for img in (img8, imgf):
+        for conv, ofn in (("nn", orc.nearest_neighbor), ("bilinear", orc.bilinear)):
+            zr, zg, ir, ig = z.copy(), z.copy(), img.copy(), img.copy()
+            ref = ofn(zr, ir, h, w, mh, mw)
+            got = hg.convertfunc[conv](zg, ig, h, w, mh, mw)
+            assert got.dtype == ref.dtype and got.shape == ref.shape == (mh, mw, chn)
+            assert np.array_equal(got, ref), (img.dtype, conv, float(np.abs(got.astype(np.float64) - ref).max()))
+            assert np.array_equal(ig, ir) and not ig[0, 0].any()        # caller's image: texel (0,0) blanked, nothing else touched
+            assert np.array_equal(zg, zr)                               # caller's z_t mutated exactly like the reference's
+    assert hg.bilinear is hg.convertfunc["bilinear"] and hg.nearestNeighbor is hg.convertfunc["nn"]
+
+
 def test_stitching_with_injected_matches(gpu, matches):
     """Config 4 driver at native size: RANSAC (app.py parameters) + warp + 'Rate' blend == reference canvas."""
     import ransac as rs
@@ -761,14 +827,20 @@ def test_config5_batch_1080p(gpu):
             assert torch.equal(per[i], kernels.warp_backward(src[i].contiguous(), invs[i], grid, (1080, 1920), interp, dt)), (interp, i)
 
 
-def _oracle_warp_on_grid(img, inv_h, xs, ys, bound_hw):
+def _oracle_warp_on_grid(img, inv_h, xs, ys, bound_hw, snap=0.0):
     """numpy float64 restatement of homography.py:166-179 for an arbitrary output grid (the oracle's own
-    interpolator on coordinates computed exactly like the reference computes them)."""
+    interpolator on coordinates computed exactly like the reference computes them).  snap > 0: coordinates within `snap` of a
+    mask edge are moved onto it first (what a kernel that rounds coordinates onto a grid of that pitch sees)."""
     from oracle import rwh_oracle as orc
     xv, yv = np.meshgrid(xs, ys)
     z = np.dstack([xv, yv, np.ones(xv.shape)]).reshape([xv.size, 3]).T
     z_t = inv_h @ z
     z_t /= z_t[-1, :]
+    if snap:
+        for row, lim in ((0, bound_hw[1] - 1.0), (1, bound_hw[0] - 1.0)):
+            v = z_t[row]
+            v[np.abs(v) <= snap] = 0.0
+            v[np.abs(v - lim) <= snap] = lim
     return orc.bilinear(z_t, img.copy(), bound_hw[0], bound_hw[1], len(ys), len(xs))
 
 
@@ -800,6 +872,48 @@ def test_warp_fallback_paths_vs_oracle(gpu, case):
     u8 = kernels.warp_backward(src, inv, grid, (300, 420), "bilinear", torch.uint8).cpu().numpy()
     d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
     assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (case, int((d > 1).sum()), float((d != 0).mean()))
+
+
+@pytest.mark.parametrize("case", ["mirror_x", "rot90", "rot180", "shift_eps"])
+def test_warp_image_edge_band_vs_oracle(gpu, case):
+    """Axis-aligned maps put whole output rows / columns ON the mask edge, and inv(H) round-off (rot180: sin(pi) = 1.2e-16)
+    or a 1e-11 px shift puts them a hair off it.  Contract (include/rwh.h): the EXACT kernel takes the reference's decision
+    bit for bit everywhere; the fast kernels agree with the reference on every pixel whose float64 coordinate is farther
+    than 2^-32 px from a mask edge, and inside that band return either the reference's value or the edge texel's blend.
+    (The bounds are 2 texels inside the image so that the reference's own +1 taps never raise IndexError.)"""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(77)
+    img = rng.integers(1, 256, (200, 300, 3), dtype=np.uint8)           # no zeros: a masked pixel is unmistakable
+    h, w = 198, 298                                                      # the `h, w` of the interpolator call (bounds)
+    if case == "mirror_x":
+        H = np.array([[-1.0, 0.0, w - 1.0], [0.0, 1.0, 0.0], [0.0, 0.0, 1.0]])
+    elif case == "rot90":
+        H = np.array([[0.0, -1.0, h - 1.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    elif case == "rot180":
+        t = np.pi
+        H = np.array([[np.cos(t), -np.sin(t), w - 1.0], [np.sin(t), np.cos(t), h - 1.0], [0.0, 0.0, 1.0]])
+    else:
+        H = np.array([[1.0, 0.0, 1e-11], [0.0, 1.0, -1e-11], [0.0, 0.0, 1.0]])
+    inv = np.linalg.inv(H)
+    xs = np.arange(-3.0, 305.0); ys = np.arange(-2.0, 204.0)
+    ref = _oracle_warp_on_grid(img, inv, xs, ys, (h, w))
+    xv, yv = np.meshgrid(xs, ys)
+    z = inv @ np.dstack([xv, yv, np.ones(xv.shape)]).reshape([xv.size, 3]).T
+    z /= z[-1]
+    sx, sy = z[0].reshape(xv.shape), z[1].reshape(xv.shape)
+    eps = 2.0 ** -32
+    band = (np.abs(sx) <= eps) | (np.abs(sx - (w - 1)) <= eps) | (np.abs(sy) <= eps) | (np.abs(sy - (h - 1)) <= eps)
+    assert band.sum() >= 200                                            # whole border rows / columns sit in the band
+    src = torch.from_numpy(img.copy()).to(gpu)
+    grid = kernels.Grid(xs[0], xs[-1], len(xs), ys[0], ys[-1], len(ys))
+    exact = kernels.warp_backward(src, inv, grid, (h, w), "bilinear", torch.float64, zero_origin=True, exact=True).cpu().numpy()
+    assert np.array_equal(exact, ref), case
+    got = kernels.warp_backward(src, inv, grid, (h, w), "bilinear", torch.float32, zero_origin=True).cpu().numpy()
+    ok = close(got, ref).all(axis=2)
+    assert ok[~band].all(), (case, int((~ok[~band]).sum()))
+    # inside the band: the reference's value (0 when it masks) or the blend the unmasked coordinate gives
+    clipped = _oracle_warp_on_grid(img, inv, xs, ys, (h, w), snap=eps)
+    assert (ok | close(got, clipped).all(axis=2))[band].all(), case
 
 
 @pytest.mark.parametrize("shape", ["7", "6", "5", None])
