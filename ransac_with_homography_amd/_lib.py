@@ -15,6 +15,7 @@ RWH_NEAREST, RWH_BILINEAR = 0, 1
 RWH_LOSS = {"fwd": 0, "backward": 1, "reproj": 2}
 RWH_WARP_ZERO_ORIGIN = 1
 RWH_WARP_EXACT = 2
+RWH_STITCH_FAST = 4
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR = 1, 2
 RWH_BATCH_DEVICE_SAMPLING = 1
 RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW = 0, 1

@@ -6,8 +6,12 @@
 // Every canvas pixel evaluates the reference's float64 arithmetic in the reference's order (the warp part is
 // warp_exact's recipe, rwh_warp.hip), so the uint8 canvas is bit-identical to stitchPanorama's.
 #include "rwh_common.h"
+#include "rwh_warp_rgb8.h"
 
 namespace rwh {
+
+int warp_composite(const unsigned char* d_img_t, int t_h, int t_w, const double* inv_h, double x0, double y0, int canvas_h,
+                   int canvas_w, unsigned char* d_canvas, const CompArgs& comp, hipStream_t s);   // rwh_warp.hip
 
 struct StitchArgs {
     const unsigned char* src_t;   // imgT, ht_src x wt_src x 3 uint8 (texel (0,0) already blanked)
@@ -108,6 +112,19 @@ extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const 
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (flags & RWH_WARP_ZERO_ORIGIN) {
         if (hipMemsetAsync(const_cast<void*>(d_img_t), 0, 3, s) != hipSuccess) return RWH_E_LAUNCH;
+    }
+    if (flags & RWH_STITCH_FAST) {
+        // the reference's float32 alphas (see below), then the two weight pairs of the mean in float64 -> float32
+        const double ta = (double)(float)(rate + 1e-10), qa_in = (double)(float)(1 + 1e-10 - rate), qa_out = (double)(float)1e-10;
+        CompArgs c;
+        c.q = static_cast<const unsigned char*>(d_img_q);
+        c.q_w = q_w; c.q_h = q_h; c.qsx = qsx; c.qsy = qsy; c.tsx = tsx; c.tsy = tsy; c.wt = warp_w; c.ht = warp_h;
+        c.mode = blend ? 2 : 1;
+        c.wq_in = (float)(qa_in / (qa_in + ta)); c.wt_in = (float)(ta / (qa_in + ta));
+        c.wq_out = (float)(qa_out / (qa_out + ta)); c.wt_out = (float)(ta / (qa_out + ta));
+        const int st = warp_composite(static_cast<const unsigned char*>(d_img_t), t_h, t_w, inv_h, (double)(grid_x0 - tsx),
+                                      (double)(grid_y0 - tsy), canvas_h, canvas_w, static_cast<unsigned char*>(d_canvas), c, s);
+        if (st != RWH_E_UNSUPPORTED) return st;     // else: a shape the staged kernel does not take -> the exact kernel
     }
     StitchArgs a;
     a.src_t = static_cast<const unsigned char*>(d_img_t);

@@ -370,8 +370,11 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // texels).  The choice is a function of the homography and the WHOLE output grid only -- never of the row shard or the
 // batch -- so that shards, batches and single launches of the same warp run the same arithmetic and agree bit for bit.
 // rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 5|6|7) overrides (tests, lab).
-static int choose_shape(const FastArgs& a) {
+// (r0, c0, nr, nc): the part of the output grid the samples are taken from (the compositor's canvas extends past the warped
+// image's rectangle, where the map means nothing); default: the whole grid.
+static int choose_shape(const FastArgs& a, int r0 = 0, int c0 = 0, int nr = -1, int nc = -1) {
     if (g_force_warp_shape) return g_force_warp_shape;
+    if (nr < 0) { nr = a.out_h; nc = a.out_w; }
     int best = 0;
     double best_lines = 1e300;
     const int order[3] = {6, 7, 5};
@@ -381,10 +384,10 @@ static int choose_shape(const FastArgs& a) {
         double lines_sum = 0;
         for (int i = 0; i < 5; ++i)
             for (int j = 0; j < 5; ++j) {
-                const double r = (a.out_h > ph ? (a.out_h - ph) * (i / 4.0) : 0.0), c = (a.out_w > pw ? (a.out_w - pw) * (j / 4.0) : 0.0);
-                long long nr, nt; double ln;
-                if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &nr, &nt, &ln)) continue;   // horizon: gathers anyway
-                ++seen; fit += f8_window_fits(lp, nr, nt); lines_sum += ln;
+                const double r = r0 + (nr > ph ? (nr - ph) * (i / 4.0) : 0.0), c = c0 + (nc > pw ? (nc - pw) * (j / 4.0) : 0.0);
+                long long fr, ft; double ln;
+                if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c), pw, ph, &fr, &ft, &ln)) continue;   // horizon: gathers anyway
+                ++seen; fit += f8_window_fits(lp, fr, ft); lines_sum += ln;
             }
         if (seen == 0) return 6;
         if (10 * fit < 9 * seen) continue;
@@ -419,7 +422,7 @@ static void fill_offsets(Coef& c, int shape, int pstr) {
 // (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on the 8 px kernel's 128 x 16 block tiles.)
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
                 int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
-                void (*custom)(const FastArgs) = nullptr, int n_h = 1) {
+                void (*custom)(const FastArgs) = nullptr, int n_h = 1, const CompArgs* comp = nullptr) {
     const bool px8 = variant >= 1, nn = variant == 3;
     if (w.out_w < (px8 ? 128 : FP_PX) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
     if (n_h != 1 && (!px8 || custom)) return RWH_E_UNSUPPORTED;
@@ -437,7 +440,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     if (px8) {
         for (int i = 0; i < n_h; ++i) {
             fill_coef(a.c, ih + 9 * i, x0, step_x, y0, step_y);
-            shape = choose_shape(a);
+            shape = comp ? choose_shape(a, comp->tsy, comp->tsx, comp->ht, comp->wt) : choose_shape(a);
             if (n_h > 1) { shape_of[i] = shape; shapes[shape - 5] = 1; }
         }
     }
@@ -471,6 +474,13 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
             else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
             else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
             else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
+        }
+        if (comp) {      // canvas compositor: the 8 px kernel with the paste / 'Rate' epilogue (uint8, one image)
+            if (!px8 || nn || !u8 || batch != 1) return RWH_E_UNSUPPORTED;
+            if (plan_only("rwh::warp_rgb8_comp<%.0s%d>", "", shape)) return RWH_OK;
+            void (*ck)(const FastArgs, const CompArgs) = shape == 7 ? warp_rgb8_comp<7> : shape == 6 ? warp_rgb8_comp<6> : warp_rgb8_comp<5>;
+            hipLaunchKernelGGL(ck, dim3(8u * a.cpx), block, 0, s, a, *comp);
+            return check_launch();
         }
         if (custom ? false : nn ? plan_only("rwh::warp_rgb8_nn<%.0s%d>", "", shape)
                           : !px8 ? plan_only("rwh::warp_rgb8_fast<%s>", u8 ? "unsigned char" : "float")
@@ -507,6 +517,22 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         }
     }
     return RWH_OK;
+}
+
+// Fast form of rwh_stitch_panorama (rwh_stitch.hip): imgT warped onto the canvas grid by the staged 8 px kernel, imgQ
+// composited in its epilogue.  (x0, y0) = the warp-grid coordinate of canvas pixel (0, 0).
+int warp_composite(const unsigned char* d_img_t, int t_h, int t_w, const double* inv_h, double x0, double y0, int canvas_h,
+                   int canvas_w, unsigned char* d_canvas, const CompArgs& comp, hipStream_t s) {
+    if (canvas_w < 128 || (size_t)t_h * t_w * 3 >= (1ull << 32)) return RWH_E_UNSUPPORTED;
+    WarpArgs a;
+    a.src = d_img_t; a.dst = d_canvas;
+    a.src_img_stride = 0; a.dst_img_stride = 0;
+    for (int i = 0; i < 9; ++i) a.ih[i] = inv_h[i];
+    a.x0 = x0; a.step_x = 1.0; a.x_last = x0 + (double)(canvas_w - 1);
+    a.y0 = y0; a.step_y = 1.0; a.y_last = y0 + (double)(canvas_h - 1);
+    a.src_h = t_h; a.src_w = t_w; a.bound_h = t_h; a.bound_w = t_w;
+    a.out_h = canvas_h; a.out_w = canvas_w; a.row_begin = 0; a.rows = canvas_h;
+    return launch_fast(a, inv_h, x0, 1.0, y0, 1.0, RWH_U8, 1, s, /*variant=*/1, 1, nullptr, 1, &comp);
 }
 
 }  // namespace rwh

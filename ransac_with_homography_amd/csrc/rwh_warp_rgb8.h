@@ -135,16 +135,12 @@ __device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, floa
 // the group's 4*PSTR pixels are re-dealt so that lane l stores the 16-byte pieces l, PSTR + l, 2*PSTR + l of the
 // group's contiguous 48*PSTR-byte row segment: three fully coalesced dwordx4 stores instead of four 12-byte ones
 // (the texture-address path, 87 % busy on this variant, charges a dwordx3 like a dwordx4).
-template <typename DstT, int PSTR = 1>
-__device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
-                                            const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
-                                            const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
-                                            const float (&wy0)[FP_PX], const float (&wy1)[FP_PX],
-                                            DstT* drow, bool store_any, int shift, unsigned char* xpose = nullptr,
-                                            int group = 0, int l = 0) {
-    constexpr bool U8 = sizeof(DstT) == 1;
+template <bool U8>
+__device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
+                                       const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
+                                       const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
+                                       const float (&wy0)[FP_PX], const float (&wy1)[FP_PX], float (&o)[FP_PX][3]) {
     constexpr float BIAS = U8 ? U8_BIAS : 0.f;
-    float o[FP_PX][3];
 #pragma unroll
     for (int j = 0; j < FP_PX; j += 2) {
         const f2 WX0 = {wx0[j], wx0[j + 1]}, WX1 = {wx1[j], wx1[j + 1]};
@@ -161,6 +157,18 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             o[j][k] = acc.x; o[j + 1][k] = acc.y;
         }
     }
+}
+
+template <typename DstT, int PSTR = 1>
+__device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
+                                            const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
+                                            const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
+                                            const float (&wy0)[FP_PX], const float (&wy1)[FP_PX],
+                                            DstT* drow, bool store_any, int shift, unsigned char* xpose = nullptr,
+                                            int group = 0, int l = 0) {
+    constexpr bool U8 = sizeof(DstT) == 1;
+    float o[FP_PX][3];
+    blend4<U8>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
     if (!store_any && !xpose) return;
 #ifdef RWH_ABL_NOSTORE  // tools/warp_lab ablation hook (never defined in the product build)
     if (o[0][0] + o[1][1] + o[2][2] + o[3][0] != -12345.f) return;
@@ -414,6 +422,83 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
 }
 
 
+// ---- canvas compositor (stitchPanorama's paste / 'Rate' blend as the warp's epilogue) ---------------
+// The launch's output grid IS the canvas (homography.py:303-321): the warped image imgT occupies the rectangle T, imgQ the
+// rectangle Q.  Paste (homography.py:335-338): Q over warped T over 0.  'Rate' (322-334): inside T the alpha-weighted mean
+// (qa * Q + ta * warped) / (qa + ta) with qa = 1 + 1e-10 - rate inside Q, 1e-10 outside (Q's colour = 0 there) and ta = the
+// warped alpha plane = rate + 1e-10 wherever the source coordinate is inside imgT, 0 where it is masked (then the result is
+// Q's pixel itself); outside T the canvas keeps Q / 0.  The fast form takes ta = its nominal value (the reference's float64
+// lerp of a constant plane is that value to 1e-16; the one output pixel whose taps include the blanked alpha texel (0,0)
+// differs) and blends in float32: within 1 LSB of the reference's uint8 canvas.
+struct CompArgs {
+    const unsigned char* q;              // imgQ, q_h x q_w x 3 uint8
+    int q_w, q_h, qsx, qsy;              // Q's rectangle on the canvas
+    int tsx, tsy, wt, ht;                // T's rectangle on the canvas (the bounding box wrapPerspective warps into)
+    int mode;                            // 1 = paste, 2 = 'Rate' blend
+    float wq_in, wt_in, wq_out, wt_out;  // qa / (qa + ta), ta / (qa + ta) inside / outside Q
+};
+
+// imgQ's pixels under a run of 4 canvas pixels (row cy, columns cx .. cx+3): 24-bit RGB each, and which of them lie in Q
+__device__ __forceinline__ unsigned comp_load_q(const CompArgs& c, int cy, int cx, uint32_t (&q)[FP_PX]) {
+    const int qy = cy - c.qsy, qx = cx - c.qsx;
+    unsigned in = 0;
+#pragma unroll
+    for (int j = 0; j < FP_PX; ++j) { q[j] = 0u; in |= (unsigned)((qy >= 0) & (qy < c.q_h) & (qx + j >= 0) & (qx + j < c.q_w)) << j; }
+    if (in == 15u) {
+        const unsigned char* p = c.q + ((size_t)qy * (size_t)c.q_w + (size_t)qx) * 3u;
+        pk3 w;
+        __builtin_memcpy(&w, p, 12);
+        q[0] = w.a & 0xFFFFFFu; q[1] = __builtin_amdgcn_alignbyte(w.b, w.a, 3) & 0xFFFFFFu;
+        q[2] = __builtin_amdgcn_alignbyte(w.c, w.b, 2) & 0xFFFFFFu; q[3] = w.c >> 8;
+    } else if (in) {
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j)
+            if (in & (1u << j)) {
+                const unsigned char* p = c.q + ((size_t)qy * (size_t)c.q_w + (size_t)(qx + j)) * 3u;
+                q[j] = p[0] | (p[1] << 8) | (p[2] << 16);
+            }
+    }
+    return in;
+}
+
+// Composite a run of 4 canvas pixels and store it.  o: the warp's float32 blends (U8_BIAS included); tin: bit j = pixel j
+// lies in T and its source coordinate is inside imgT; qin / q: from comp_load_q; `first`: ragged-row start as in blend_store.
+__device__ __forceinline__ void comp_store(const CompArgs& c, const float (&o)[FP_PX][3], unsigned tin, unsigned qin,
+                                           const uint32_t (&q)[FP_PX], unsigned char* drow, bool store_any, int first) {
+    uint32_t px[FP_PX];
+#pragma unroll
+    for (int j = 0; j < FP_PX; ++j) {
+        const bool t = tin & (1u << j), in_q = qin & (1u << j);
+        uint32_t v = 0u;
+        if (c.mode == 1) {                                     // paste: Q over the truncated warp over 0
+            v = __builtin_amdgcn_cvt_pk_u8_f32(o[j][0], 0, v); v = __builtin_amdgcn_cvt_pk_u8_f32(o[j][1], 1, v);
+            v = __builtin_amdgcn_cvt_pk_u8_f32(o[j][2], 2, v);
+            v = in_q ? q[j] : (t ? v : 0u);
+        } else {                                               // v = wq * Q + wt * warp, truncated (bias trick as in blend_store)
+            const float wq = t ? (in_q ? c.wq_in : c.wq_out) : 1.f, wt = t ? (in_q ? c.wt_in : c.wt_out) : 0.f;
+            const float kb = U8_BIAS - U8_BIAS * wt;           // o carries U8_BIAS once: wt * (o - BIAS) + BIAS + wq * Q
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const float cq = (float)((q[j] >> (8 * k)) & 0xFFu);
+                v = __builtin_amdgcn_cvt_pk_u8_f32(__builtin_fmaf(wt, o[j][k], __builtin_fmaf(wq, cq, kb)), k, v);
+            }
+        }
+        px[j] = v;
+    }
+    if (!store_any) return;
+    if (first <= 0) {
+        pk3 w;
+        w.a = (px[0] & 0xFFFFFFu) | (px[1] << 24);
+        w.b = ((px[1] >> 8) & 0xFFFFu) | (px[2] << 16);
+        w.c = ((px[2] >> 16) & 0xFFu) | (px[3] << 8);
+        __builtin_memcpy(drow, &w, 12);
+    } else {
+#pragma unroll
+        for (int j = 1; j < FP_PX; ++j)
+            if (j >= first) { drow[3 * j] = (unsigned char)px[j]; drow[3 * j + 1] = (unsigned char)(px[j] >> 8); drow[3 * j + 2] = (unsigned char)(px[j] >> 16); }
+    }
+}
+
 // ---- 8 pixels per lane: one wave = a 512-pixel output patch, one block = 4 waves = a 128 x 16 output tile ----------
 // Same arithmetic as warp_rgb8_fast, but the per-lane overhead (patch decode, coordinate setup, footprint,
 // staging set-up) is shared by twice as many pixels, and the patch SHAPE is a template parameter:
@@ -462,8 +547,8 @@ inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // h
 // occupancy-sensitive (time ~ 9.5 + 35/n us per 4K frame for n resident waves per SIMD, n <= 5 measured) and this
 // keeps it at 6 waves (LDS-limited).  The end pixels are computed once, so the footprint and the taps can never
 // disagree about a floor().
-template <typename DstT, int LOG_PW>
-__device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
+template <typename DstT, int LOG_PW, bool COMP = false>
+__device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, const CompArgs* cp = nullptr) {
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
     constexpr int LPR = PW / 8;                             // lanes per patch row
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
@@ -506,6 +591,40 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
     DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
     const uint32_t pitch = (uint32_t)a.src_w * 3u;
+
+    // ---- compositor: where does this wave's patch lie relative to the rectangles T and Q? (uniform) ---------------------
+    bool all_t = true;
+    const int cy = a.row_begin + rr;                          // the lane's canvas row
+    if constexpr (COMP) {
+        const CompArgs& c = *cp;
+        const int px0 = tcol + wave_x, px1 = px0 + PW - 1;                         // patch columns (inclusive)
+        const int py0 = a.row_begin + min((int)ty * 16 + wave_y, a.rows - 1), py1 = a.row_begin + min((int)ty * 16 + wave_y + PH - 1, a.rows - 1);
+        const bool none_t = (px1 < c.tsx) | (px0 >= c.tsx + c.wt) | (py1 < c.tsy) | (py0 >= c.tsy + c.ht);
+        all_t = (px0 >= c.tsx) & (px1 < c.tsx + c.wt) & (py0 >= c.tsy) & (py1 < c.tsy + c.ht);
+        const bool all_q = (px0 >= c.qsx) & (px1 < c.qsx + c.q_w) & (py0 >= c.qsy) & (py1 < c.qsy + c.q_h);
+        if (none_t | ((c.mode == 1) & all_q)) {               // nothing of the warp shows: Q's pixels or 0
+            if (all_q & (tshift == 0)) {                          // a patch inside Q: a plain 12-byte copy per run
+                const unsigned char* qrow = c.q + ((size_t)(cy - c.qsy) * (size_t)c.q_w + (size_t)(c0p - c.qsx)) * 3u;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    pk3 w;
+                    __builtin_memcpy(&w, qrow + 3 * (PW / 2) * h, 12);
+                    if (store_any) __builtin_memcpy(reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, &w, 12);
+                }
+                return;
+            }
+            const float zero[FP_PX][3] = {};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t q[FP_PX];
+                const unsigned qin = comp_load_q(c, cy, c0p + (PW / 2) * h, q);
+                const int first = tshift - (lcol + (PW / 2) * h);
+                CompArgs cc = c; cc.mode = 1;                 // (paste rule: Q, else 0 -- also what 'Rate' leaves outside T)
+                comp_store(cc, zero, 0u, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
+            }
+            return;
+        }
+    }
 
     // ---- pixels 0 and 7 of the lane: own reciprocal ------------------------------------------------------------
     const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
@@ -646,6 +765,20 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
                 unsigned char* xp = tshift == 0 ? my + F8_SLAB : nullptr;
                 blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
                                         xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
+            } else if constexpr (COMP) {
+                float o[FP_PX][3];
+                blend4<true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
+                uint32_t q[FP_PX];
+                const int cx = c0p + (PW / 2) * h;
+                const unsigned qin = comp_load_q(*cp, cy, cx, q);
+                unsigned tin = 15u;                           // staged: every source coordinate is inside imgT
+                if (!all_t) {
+                    tin = 0u;
+#pragma unroll
+                    for (int j = 0; j < FP_PX; ++j)
+                        tin |= (unsigned)((cy >= cp->tsy) & (cy < cp->tsy + cp->ht) & (cx + j >= cp->tsx) & (cx + j < cp->tsx + cp->wt)) << j;
+                }
+                comp_store(*cp, o, tin, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
             } else {
                 blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
                                         store_any & (first <= 3 * PSTR), max(first, 0));
@@ -659,6 +792,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
     for (int h = 0; h < 2; ++h) {
         uint32_t off[FP_PX];
         bool near_end = false;
+        unsigned vbits = 0u;
         run_coords(h);
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j) {
@@ -670,6 +804,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
             weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
             off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
             near_end |= valid & (iy > a.src_h - 3);
+            vbits |= (unsigned)valid << j;
         }
         if (!__any(near_end)) {
 #pragma unroll
@@ -692,13 +827,35 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab) {
             }
         }
         const int first = tshift - (lcol + (PW / 2) * h);
-        blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
-                                store_any & (first <= 3 * PSTR), max(first, 0));
+        if constexpr (COMP) {
+            float o[FP_PX][3];
+            blend4<true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
+            uint32_t q[FP_PX];
+            const int cx = c0p + (PW / 2) * h;
+            const unsigned qin = comp_load_q(*cp, cy, cx, q);
+            unsigned tin = 0u;
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j)
+                tin |= (unsigned)((cy >= cp->tsy) & (cy < cp->tsy + cp->ht) & (cx + j >= cp->tsx) & (cx + j < cp->tsx + cp->wt)) << j;
+            // a pixel outside T never shows the warp, whatever its coordinate maps to (T is the reference's int()-truncated bbox)
+            float oz[FP_PX][3];
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) oz[j][k] = (tin & (1u << j)) ? o[j][k] : U8_BIAS;
+            comp_store(*cp, oz, tin & vbits, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
+        } else {
+            blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                                    store_any & (first <= 3 * PSTR), max(first, 0));
+        }
     }
 }
 
 template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+// canvas compositor form (uint8): the output grid is the canvas, imgQ is composited in the epilogue (CompArgs)
+template <int LOG_PW>
+__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_comp(const FastArgs a, const CompArgs c) { fast8_body<unsigned char, LOG_PW, true>(a, nullptr, &c); }
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }

@@ -398,8 +398,10 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     exactly as in the reference (always bilinear).
 
     uint8 RGB images with blending False or 'Rate' run in ONE fused kernel (`rwh_stitch_panorama`): alpha plane,
-    warp, paste / alpha blend per canvas pixel in the reference's float64 arithmetic -- the canvas is bit-identical
-    to the reference's and nothing intermediate (RGBA float32 image, float64 warp, float32 canvas) is materialised."""
+    warp, paste / alpha blend per canvas pixel; nothing intermediate (RGBA float32 image, float64 warp, float32 canvas)
+    is materialised.  numpy arrays in (or EXACT = True): the reference's float64 arithmetic, canvas bit-identical to the
+    reference's; torch tensors in (or EXACT = False): the staged fast warp kernel with the compositor as its epilogue,
+    canvas within 1 LSB."""
     import torch
     fused = (blending is False or blending is None or blending == 0 or blending == 'Rate')
     tens = _is_tensor(imgQ) or _is_tensor(imgT)
@@ -428,8 +430,9 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     else:
         t_dev = torch.from_numpy(np.ascontiguousarray(imgT)).to(dev)
         q_dev = torch.from_numpy(np.ascontiguousarray(imgQ)).to(dev)
+    exact = (not tens) if EXACT is None else bool(EXACT)    # numpy in: the bit-identical float64 kernel; tensors in: the fast one
     out = kernels.stitch_panorama(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), (fh, fw),
-                                  bool(blending), blendrate, zero_origin=True)
+                                  bool(blending), blendrate, zero_origin=True, fast=not exact)
     if tens:
         return out
     if not blending:

@@ -735,7 +735,53 @@ def test_stitching_with_injected_matches(gpu, matches):
     check_pick(z, "stitch_g5_rate", out, exact=False)
 
 
-def test_config4_panorama_8k_end_to_end(gpu, matches):
+@pytest.mark.parametrize("blending", [False, "Rate"])
+def test_fast_compositor_vs_reference_and_exact(gpu, blending):
+    """stitchPanorama on tensors = the staged warp kernel with the compositor epilogue (rwh::warp_rgb8_comp): the canvas is
+    within 1 LSB of the reference's (G8 picks, native size, both homographies) and of the exact float64 kernel's on the x8
+    canvas (13 181 x 6 313), where it must also reproduce imgQ's pixels and the empty corners exactly."""
+    import homography as hg
+    import ransac_with_homography_amd.homography as impl
+    z = load_golden("g8_stitch")
+    f = load_golden("img_foto1")
+    A, B = torch.from_numpy(f["A"].copy()).to(gpu), torch.from_numpy(f["B"].copy()).to(gpu)
+    key = "stitch_rate" if blending else "stitch_paste"
+    out = hg.stitchPanorama(B, A.clone(), z["H_notebook"], blending=blending, blendrate=0.2).cpu().numpy()
+    check_pick(z, key, out, exact=False)
+    if blending:
+        check_pick(z, "stitch_g5_rate", hg.stitchPanorama(B, A.clone(), z["H_g5"], blending="Rate", blendrate=0.2).cpu().numpy(), exact=False)
+    # x8: fast (tensors) against exact (same tensors, EXACT forced)
+    A8 = torch.from_numpy(np.ascontiguousarray(np.repeat(np.repeat(f["A"], 8, axis=0), 8, axis=1))).to(gpu)
+    B8 = torch.from_numpy(np.ascontiguousarray(np.repeat(np.repeat(f["B"], 8, axis=0), 8, axis=1))).to(gpu)
+    S = np.diag([8.0, 8.0, 1.0])
+    H8 = S @ z["H_g5"] @ np.linalg.inv(S)
+    fast = hg.stitchPanorama(B8, A8.clone(), H8, blending=blending, blendrate=0.2)
+    old = impl.EXACT
+    impl.EXACT = True
+    try:
+        exact = hg.stitchPanorama(B8, A8.clone(), H8, blending=blending, blendrate=0.2)
+    finally:
+        impl.EXACT = old
+    assert fast.shape == exact.shape and fast.dtype == torch.uint8
+    d = (fast.to(torch.int16) - exact.to(torch.int16)).abs()
+    nbad = int((d > 1).sum())
+    assert nbad <= 24, nbad                                      # (the pixels around imgT's blanked alpha texel (0,0))
+    assert float((d != 0).float().mean()) < 0.12
+    from oracle import rwh_oracle as orc
+    mx, my, wt, ht = orc.output_bounds(A8.shape[0], A8.shape[1], H8, 0)
+    (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (fw, fh) = orc.stitch_geometry(wt, ht, B8.shape[1], B8.shape[0], mx, my)
+    assert tuple(fast.shape[:2]) == (fh, fw)
+    if not blending:                                             # paste: imgQ's rectangle is imgQ, bit for bit
+        assert torch.equal(fast[qsy:qey + 1, qsx:qex + 1], B8)
+    outside = torch.ones((fh, fw), dtype=torch.bool, device=gpu)  # the corners neither rectangle covers stay 0
+    outside[tsy:tey + 1, tsx:tex + 1] = False
+    outside[qsy:qey + 1, qsx:qex + 1] = False
+    assert int(outside.sum()) > 0 and not fast[outside].any()
+    left = fast[qsy:qey + 1, qsx:min(tsx, qex + 1)]              # imgQ's part outside T: untouched by the blend too
+    assert torch.equal(left, B8[:, : left.shape[1]])
+
+
+def test_config4_panorama_8k_end_to_end(gpu, matches, auto_mode):
     """BASELINE config 4: foto1A/foto1B upsampled x8 (8192x5464), RANSAC (app.py parameters, threshold
     scaled with the image) + warp + paste, end to end on one GPU.  Scaling by a power of two is exact
     in floating point, so the x8 problem must pick the same hypothesis with the same inlier set as the
