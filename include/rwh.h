@@ -203,6 +203,10 @@ RWH_API int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int m,
 
 /* flag for rwh_ransac_batched */
 #define RWH_BATCH_DEVICE_SAMPLING 1u /* fill d_idx on the device (Philox4x32-10) instead of reading the caller's table */
+#define RWH_BATCH_EARLY_STOP 2u      /* the `break` of ransac.py:186-190 as saved work: once a hypothesis of a problem has reached
+                                        its `need`, scorer waves of LATER hypotheses of that problem skip (their d_counts entry is
+                                        -1, their mask words 0).  The winner is unchanged -- the lowest index that reaches `need`
+                                        -- because a skipped hypothesis always has a lower-index exit on record. */
 
 /*
  * Many independent RANSAC searches in one submission (no counterpart in the reference,

@@ -18,6 +18,7 @@ RWH_WARP_EXACT = 2
 RWH_STITCH_FAST = 4
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR = 1, 2
 RWH_BATCH_DEVICE_SAMPLING = 1
+RWH_BATCH_EARLY_STOP = 2
 RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW = 0, 1
 
 # every symbol include/rwh.h declares (tests check the library exports them all)

@@ -287,7 +287,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
                                                     const float* __restrict__ pb, int m, int k, int hpw, double th,
                                                     float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
                                                     float* __restrict__ errs, const int32_t* __restrict__ offsets,
-                                                    int k_per, int mask_stride) {
+                                                    int k_per, int mask_stride, const int32_t* __restrict__ stop_needs,
+                                                    unsigned long long* stop_keys) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int h_begin, h_end;
@@ -306,6 +307,13 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
         h_end = min(k, h_begin + hpw);
     }
     const int words = (m + 63) >> 6;
+    // early stop (batched mode, RWH_BATCH_EARLY_STOP): word 1 of the problem's packed keys doubles as its "done" word --
+    // 0xFFFFFFFF - (lowest hypothesis index that reached `need` so far).  The reference stops at that hypothesis
+    // (`break`, ransac.py:186-190): later ones are never evaluated, so a wave that finds an earlier exit on record skips
+    // its hypothesis (count -1).  Waves are dispatched in index order, so most of the work after the exit disappears.
+    const int stop_p = stop_keys ? h_begin / k_per : 0;
+    const int stop_need = stop_keys ? stop_needs[stop_p] : 0;
+    unsigned long long* stop_word = stop_keys ? stop_keys + 2 * (size_t)stop_p + 1 : nullptr;
 
     float2 ra[WORDS > 0 ? WORDS : 1], rb[WORDS > 0 ? WORDS : 1];
     if constexpr (WORDS > 0) {
@@ -317,6 +325,15 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
         }
     }
     for (int hyp = h_begin; hyp < h_end; ++hyp) {
+        if (stop_word) {
+            const unsigned long long done = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int local = hyp - stop_p * k_per;
+            if (done != 0ull && (long long)(0xFFFFFFFFull - done) < (long long)local) {      // an earlier hypothesis already exits
+                if (lane == 0) counts[hyp] = -1;
+                if (masks && lane < mask_stride) masks[(size_t)hyp * mask_stride + lane] = 0;
+                continue;
+            }
+        }
         float h[9], hi[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) h[i] = hs[9 * (size_t)hyp + i];   // uniform address: scalar loads
@@ -359,7 +376,10 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
             if (masks && lane == 0)
                 for (int w = words; w < mask_stride; ++w) masks[(size_t)hyp * mask_stride + w] = 0;
         }
-        if (lane == 0) counts[hyp] = count;
+        if (lane == 0) {
+            counts[hyp] = count;
+            if (stop_word && count >= stop_need) atomicMax(stop_word, 0xFFFFFFFFull - (unsigned long long)(hyp - stop_p * k_per));
+        }
     }
 }
 
@@ -379,7 +399,7 @@ __global__ __launch_bounds__(256) void argmax_kernel(const int32_t* __restrict__
     const int c0 = blockIdx.x * chunk, c1 = min(k, c0 + chunk);
     unsigned long long key0 = 0, key1 = 0;
     for (int i = c0 + (int)threadIdx.x; i < c1; i += 256) {
-        const int c = counts[i];
+        const int c = max(counts[i], 0);                      // -1 = skipped after an early exit (RWH_BATCH_EARLY_STOP)
         const unsigned long long inv_idx = 0xFFFFFFFFull - (unsigned long long)(hyp_base + i);
         const unsigned long long key = ((unsigned long long)(unsigned)c << 32) | inv_idx;
         key0 = key > key0 ? key : key0;
@@ -514,12 +534,13 @@ static float score_sq_limit(double th) {
 template <int LOSS>
 void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
                   int hpw, double th, int32_t* d_counts, uint64_t* d_masks, float* d_err,
-                  const int32_t* offsets = nullptr, int k_per = 0, int mask_stride = -1) {
+                  const int32_t* offsets = nullptr, int k_per = 0, int mask_stride = -1,
+                  const int32_t* stop_needs = nullptr, unsigned long long* stop_keys = nullptr) {
     const dim3 block(256);
     if (mask_stride < 0) mask_stride = words;
     const float sq_limit = score_sq_limit(th);
 #define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, \
-                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride)
+                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride, stop_needs, stop_keys)
     switch (words <= 4 ? words : 0) {
         case 1: RWH_SCORE(1); break;
         case 2: RWH_SCORE(2); break;
@@ -595,12 +616,14 @@ extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, co
     const long long waves = (long long)n_problems * ((k + hpw - 1) / hpw);
     const dim3 grid((unsigned)((waves + 3) / 4));
     const int words = (m_max + 63) / 64;
+    const int32_t* sn = (flags & RWH_BATCH_EARLY_STOP) ? d_need : nullptr;
+    unsigned long long* sk = (flags & RWH_BATCH_EARLY_STOP) ? reinterpret_cast<unsigned long long*>(d_best) : nullptr;
     if (loss == RWH_LOSS_FWD)
-        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words);
+        launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words, sn, sk);
     else if (loss == RWH_LOSS_BACKWARD)
-        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words);
+        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words, sn, sk);
     else
-        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words);
+        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m_max, (int)total, hpw, th, d_counts, d_masks, nullptr, d_offsets, k, words, sn, sk);
     launch_argmax(s, d_counts, (int)total, n_problems, k, 0, d_need, 0, reinterpret_cast<unsigned long long*>(d_best));
     return check_launch();
 }

@@ -187,7 +187,7 @@ class BatchWorkspace:
         self.best = torch.zeros((n_problems, 2), dtype=torch.int64, device=device)
 
 
-def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=None, problem_base=0):
+def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=None, problem_base=0, early_stop=False):
     """P independent RANSAC searches in one library call (rwh_ransac_batched, include/rwh.h).
 
     pts_a/pts_b: [total,2] float32 (the problems' correspondences concatenated), offsets: [P+1] int32,
@@ -200,9 +200,9 @@ def ransac_batched(pts_a, pts_b, offsets, needs, th, loss, ws, seed=None, idx=No
     assert (seed is None) != (idx is None), "give exactly one of seed= (device sampling) and idx= (caller's samples)"
     P = offsets.shape[0] - 1
     assert P == ws.p and needs.shape[0] == P and offsets.dtype == torch.int32 and needs.dtype == torch.int32
-    flags = 0
+    flags = _lib.RWH_BATCH_EARLY_STOP if early_stop else 0     # hypotheses after a problem's early exit are skipped (count -1)
     if idx is None:
-        flags = _lib.RWH_BATCH_DEVICE_SAMPLING
+        flags |= _lib.RWH_BATCH_DEVICE_SAMPLING
     else:
         assert tuple(idx.shape) == (P, ws.k, 4) and idx.dtype == torch.int32
         ws.idx.copy_(idx)

@@ -317,22 +317,43 @@ class RANSAC(object):
         return finalModel, inliers, totalfit
 
 
-def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None, problem_base=0):
+class DeviceProblems(object):
+    """Correspondences that already live on the GPU (the hand-off of SURVEY.md 8f row f-3): the problems' matches
+    concatenated, pts_a / pts_b float32 [total, 2] torch tensors on the device (the `matchespoints` layout, points in rows),
+    `sizes` = correspondences per problem (host ints).  `run_batch` takes it in place of the list of [X, Y] arrays."""
+
+    def __init__(self, pts_a, pts_b, sizes):
+        import torch
+        self.sizes = [int(m) for m in sizes]
+        assert pts_a.is_cuda and pts_b.is_cuda and pts_a.dtype == torch.float32 and pts_b.dtype == torch.float32
+        assert tuple(pts_a.shape) == tuple(pts_b.shape) == (sum(self.sizes), 2)
+        self.pts_a, self.pts_b = pts_a.contiguous(), pts_b.contiguous()
+
+    def __len__(self):
+        return len(self.sizes)
+
+
+def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None, problem_base=0, refit=True, info=None):
     """RANSAC over MANY image pairs in one GPU submission (the reference has no
     counterpart: its RANSAC.run handles one pair per call, ransac.py:159-213).
 
-    datas: list of [X, Y] (each 2 x M_p or 3 x M_p, the `RANSAC.run` layout).  Returns a list of
-    `(finalModel float64 3x3, (inlier_indices,), count)` -- per problem exactly what `RANSAC.run` returns for the same
-    samples, including the final N-point refit on the host (ransac.py:206-211); `finalModel` is None for a problem
-    whose winner has too few inliers to refit (where `RANSAC.run` raises AssertionError).
+    datas: list of [X, Y] (each 2 x M_p or 3 x M_p, the `RANSAC.run` layout), or a `DeviceProblems` (correspondences
+    already on the GPU: nothing but the winners' inlier masks -- and, with refit=True, the points for the host refit --
+    comes back).  Returns a list of `(finalModel float64 3x3, (inlier_indices,), count)` -- per problem exactly what
+    `RANSAC.run` returns for the same samples, including the final N-point refit on the host (ransac.py:206-211);
+    `finalModel` is None for a problem whose winner has too few inliers to refit (where `RANSAC.run` raises
+    AssertionError) and with refit=False (no correspondence then visits the host at all).
 
     Sampling: by default on the device (Philox4x32-10 keyed by `seed`, four distinct correspondences per hypothesis):
     a documented NON-PARITY mode -- the reference draws with replacement from numpy's global legacy generator
     (ransac.py:177).  Pass `idx` (list of [k,4] integer arrays, one per problem) to supply the samples yourself; each
     problem's result then equals `RANSAC.run` on that table bit for bit.  The early-exit rule (ransac.py:186-190)
-    holds per problem either way: the first hypothesis whose count reaches M*d/100 + n wins.  `problem_base`: global
+    holds per problem either way: the first hypothesis whose count reaches M*d/100 + n wins -- and in the device-sampling
+    mode it also stops the work: scorer waves of later hypotheses of that problem skip (RWH_BATCH_EARLY_STOP; with the
+    caller's tables every hypothesis is scored, because the host settle step may move the exit).  `problem_base`: global
     index of datas[0] when a longer problem list is split over several calls (sharded.run_batch_sharded), so that the
-    device sampler draws the tables of the unsplit run."""
+    device sampler draws the tables of the unsplit run.  `info`: optional dict, receives "scored" (hypotheses actually
+    scored per problem) and "early" (per problem: did it exit early)."""
     import torch
     if method not in _lib.RWH_LOSS:
         exit("Invalid method!")
@@ -342,14 +363,19 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     P = len(datas)
     if P == 0:
         return []
-    sizes = []
-    for X, Y in datas:
-        assert X.shape[1] == Y.shape[1], "data observation not consistent!"
-        sizes.append(X.shape[1])
+    on_device = isinstance(datas, DeviceProblems)
+    if on_device:
+        sizes = datas.sizes
+        pa, pb = datas.pts_a, datas.pts_b
+    else:
+        sizes = []
+        for X, Y in datas:
+            assert X.shape[1] == Y.shape[1], "data observation not consistent!"
+            sizes.append(X.shape[1])
+        pa = torch.from_numpy(np.concatenate([_points_rows(X) for X, _ in datas])).to(dev)
+        pb = torch.from_numpy(np.concatenate([_points_rows(Y) for _, Y in datas])).to(dev)
     offsets = np.zeros(P + 1, dtype=np.int32)
     offsets[1:] = np.cumsum(sizes)
-    pa = torch.from_numpy(np.concatenate([_points_rows(X) for X, _ in datas])).to(dev)
-    pb = torch.from_numpy(np.concatenate([_points_rows(Y) for _, Y in datas])).to(dev)
     needs_host = [kernels.need_count(m, d, n) for m in sizes]
     needs = torch.tensor(needs_host, dtype=torch.int32, device=dev)
     ws = kernels.BatchWorkspace(P, int(k), max(max(sizes), 1), dev)
@@ -358,13 +384,15 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, idx=table)
     else:
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed,
-                               problem_base=problem_base)
+                               problem_base=problem_base, early_stop=True)
+    pa_host = pb_host = None
+    if idx is not None or (refit and on_device):
+        pa_host, pb_host = pa.cpu().numpy(), pb.cpu().numpy()
     if idx is not None:
         # the caller's tables may hold repeated indices (numpy's sampler draws with replacement): settle every problem
         # with the reference's solver, exactly as RANSAC.run does
         counts_host = ws.counts.cpu().numpy()
         flags_host = ws.flags.cpu().numpy()
-        pa_host, pb_host = pa.cpu().numpy(), pb.cpu().numpy()
         winners, win_counts, host_masks = [], [], []
         for p in range(P):
             o0, o1 = int(offsets[p]), int(offsets[p + 1])
@@ -380,8 +408,11 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     win_masks = ws.masks[rows[:, 0], rows[:, 1]].cpu().numpy()          # one gather, one copy for all problems
     if idx is None:
         win_counts = ws.counts[rows[:, 0], rows[:, 1]].cpu().numpy()
+    if info is not None:
+        info["scored"] = (ws.counts >= 0).sum(dim=1).cpu().numpy()
+        info["early"] = [bool(w[2]) for w in winners]
     out = []
-    for p, ((X, Y), (winner, _, early)) in enumerate(zip(datas, winners)):
+    for p, (winner, _, early) in enumerate(winners):
         model = HomoModel(th=th, d=d, n=n)
         if winner is None or int(win_counts[p]) == 0:
             inliers, total = (np.array([], dtype=np.int64),), 0
@@ -389,10 +420,17 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
             words = host_masks[p] if host_masks[p] is not None else win_masks[p]
             bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:sizes[p]]
             inliers, total = (np.nonzero(bits)[0].astype(np.int64),), np.int64(win_counts[p])
-        try:
-            H = model.fit(X[:, inliers[0]], Y[:, inliers[0]], collective=True)
-        except AssertionError:      # fewer inliers than a refit needs: RANSAC.run would raise here (ransac.py:38)
-            H = None
+        H = None
+        if refit:
+            if on_device:
+                o0 = int(offsets[p])
+                X, Y = pa_host[o0:o0 + sizes[p]].T, pb_host[o0:o0 + sizes[p]].T
+            else:
+                X, Y = datas[p]
+            try:
+                H = model.fit(X[:, inliers[0]], Y[:, inliers[0]], collective=True)
+            except AssertionError:      # fewer inliers than a refit needs: RANSAC.run would raise here (ransac.py:38)
+                H = None
         out.append((H, inliers, total))
     return out
 

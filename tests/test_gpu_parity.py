@@ -565,6 +565,60 @@ def test_batched_device_sampling(gpu, matches):
         assert int(r[2]) >= X.shape[1] * 40 / 100 + 4
 
 
+def test_batched_early_stop_and_device_handoff(gpu, matches):
+    """f-3: (i) RWH_BATCH_EARLY_STOP -- the `break` of ransac.py:186-190 as saved work: with d = 40 every problem exits early,
+    far fewer hypotheses are scored, and winner / count / mask / keys are exactly those of the run that scores everything;
+    with d = 70 (no exit) nothing is skipped; (ii) DeviceProblems: correspondences that already live on the GPU give the
+    same results as the list-of-arrays form, and with refit=False nothing but the winners' masks comes back."""
+    from ransac_with_homography_amd import kernels
+    from ransac_with_homography_amd import ransac as rmod
+    probs = _batch_problems(matches)[:4]
+    sizes = [X.shape[1] for X, _ in probs]
+    K, seed = 4096, 77
+    offsets = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.int32, device=gpu)
+    pa = torch.from_numpy(np.concatenate([np.ascontiguousarray(X.T[:, :2], np.float32) for X, _ in probs])).to(gpu)
+    pb = torch.from_numpy(np.concatenate([np.ascontiguousarray(Y.T[:, :2], np.float32) for _, Y in probs])).to(gpu)
+    for d, expect_exit in ((40, True), (70, False)):
+        needs = torch.tensor([kernels.need_count(m, d, 4) for m in sizes], dtype=torch.int32, device=gpu)
+        full = kernels.BatchWorkspace(len(probs), K, max(sizes), gpu)
+        kernels.ransac_batched(pa, pb, offsets, needs, 5.0, "fwd", full, seed=seed)
+        stop = kernels.BatchWorkspace(len(probs), K, max(sizes), gpu)
+        kernels.ransac_batched(pa, pb, offsets, needs, 5.0, "fwd", stop, seed=seed, early_stop=True)
+        # word 1 (the exit) is the same; word 0 (max count so far) is the same unless an exit cut the problem short -- the
+        # reference never looks at hypotheses past its `break` either
+        assert torch.equal(stop.best[:, 1], full.best[:, 1]) and torch.equal(stop.idx, full.idx)
+        assert expect_exit or torch.equal(stop.best, full.best)
+        for p in range(len(probs)):
+            assert kernels.decode_best(stop.best[p].cpu().numpy(), K) == kernels.decode_best(full.best[p].cpu().numpy(), K)
+        scored = (stop.counts >= 0)
+        assert torch.equal(stop.counts[scored], full.counts[scored]) and torch.equal(stop.masks[scored], full.masks[scored])
+        assert not stop.masks[~scored].any()
+        best = full.best.cpu().numpy()
+        for p in range(len(probs)):
+            w, _, early = kernels.decode_best(best[p], K)
+            assert early == expect_exit, (d, p)
+            n_scored = int(scored[p].sum())
+            if early:
+                assert bool(scored[p, : w + 1].all())            # everything up to the exit was scored
+                print("d=%d problem %d: exit at %d, scored %d of %d" % (d, p, w, n_scored, K))
+            else:
+                assert n_scored == K
+        if expect_exit:
+            # (all 16 384 waves of this small batch are resident almost at once -- 8 192 fit the chip -- so about a third
+            #  still start before the first exit is on record; the saving grows with the batch)
+            assert int(scored.sum()) < 0.6 * scored.numel()
+    # host wrapper: DeviceProblems == list of arrays, and the info dict reports the saved work
+    dp = rmod.DeviceProblems(pa, pb, sizes)
+    info = {}
+    a = rmod.run_batch(probs, th=5, d=40, k=K, method="fwd", seed=seed)
+    b = rmod.run_batch(dp, th=5, d=40, k=K, method="fwd", seed=seed, info=info)
+    c = rmod.run_batch(dp, th=5, d=40, k=K, method="fwd", seed=seed, refit=False)
+    for ra, rb, rc in zip(a, b, c):
+        assert np.array_equal(ra[0], rb[0]) and np.array_equal(ra[1][0], rb[1][0]) and int(ra[2]) == int(rb[2])
+        assert rc[0] is None and np.array_equal(rc[1][0], ra[1][0]) and int(rc[2]) == int(ra[2])
+    assert all(info["early"]) and int(info["scored"].sum()) < 0.6 * K * len(probs)
+
+
 def test_scorer_threshold_edges(gpu):
     """`err < th` is decided on the squared error against a host-computed limit (no square root per pair): the decision
     must equal the oracle's `sqrt(...) < th` for thresholds sitting exactly on, one ulp below and one ulp above
