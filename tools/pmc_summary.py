@@ -1,18 +1,23 @@
-"""Summarise rocprofv3 --pmc CSV output: per kernel, per counter: mean over the last dispatches."""
-import collections, csv, glob, os, sys
+"""Summarise rocprofv3 --pmc CSV output: per (kernel, grid size), per counter: mean over the dispatches (sum over the
+counter's instances per dispatch)."""
+import collections, csv, glob, json, os, sys
 root = sys.argv[1]
-acc = collections.defaultdict(lambda: collections.defaultdict(list))
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: collections.defaultdict(float)))
 for f in sorted(glob.glob(os.path.join(root, "pass*", "**", "*counter_collection.csv"), recursive=True)):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            acc[row["Kernel_Name"]][row["Counter_Name"]].append((int(row["Dispatch_Id"]), float(row["Counter_Value"])))
-for k, cs in acc.items():
-    if "warp" not in k and "stitch" not in k:
+            key = (row["Kernel_Name"], int(row["Grid_Size"]))
+            acc[key][row["Counter_Name"]][(f, int(row["Dispatch_Id"]))] += float(row["Counter_Value"])
+out = {}
+for (k, grid), cs in sorted(acc.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
+    if "rwh::" not in k:
         continue
-    print(k[:90])
-    for c, vals in sorted(cs.items()):
-        by = collections.defaultdict(float)
-        for d, v in vals:
-            by[d] += v
-        ds = sorted(by)[-3:]
-        print("   %-28s %16.0f   (mean of last %d of %d dispatches)" % (c, sum(by[d] for d in ds) / len(ds), len(ds), len(by)))
+    print("%s   grid %d" % (k[:100], grid))
+    out["%s|%d" % (k, grid)] = {}
+    for c, by in sorted(cs.items()):
+        vals = [by[d] for d in sorted(by)]
+        vals = vals[len(vals) // 2:] if len(vals) > 4 else vals      # second half: past the clock ramp
+        m = sum(vals) / len(vals)
+        out["%s|%d" % (k, grid)][c] = m
+        print("   %-24s %18.0f   (mean of %d dispatches)" % (c, m, len(vals)))
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1)
