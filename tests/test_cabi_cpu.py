@@ -53,6 +53,38 @@ def test_argument_validation_without_gpu(lib):
     assert st == 0
 
 
+def test_new_entry_points_validate_and_plan(lib):
+    """Round-2 entry points: NULL / bad arguments are refused before any device access, and rwh_warp_plan (the dispatch of
+    rwh_warp_backward without the launch) names the kernel each configuration gets -- no GPU needed."""
+    import torch
+    from ransac_with_homography_amd import _lib, kernels
+    null = ctypes.c_void_p(0)
+    assert lib.rwh_sample_points(null, 8, 8, 3, 0, null, null, 4, 8, 8, 1, null, 2, 0, null) == -1
+    assert lib.rwh_project_points_ex(null, null, 4, 2, null, null) == -1
+    assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, 9) == -1 and lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, 0) == 0
+    assert lib.rwh_lab_tune(_lib.RWH_TUNE_SCORE_HPW, 65) == -1 and lib.rwh_lab_tune(7, 0) == -1
+    Hs = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+    inv = np.linalg.inv(Hs)
+    g = kernels.Grid(5, 3775, 3771, 7, 2034, 2028)
+    plan = lambda shape, dt, *a, **k: kernels.warp_plan(shape, dt, inv, g, (2160, 3840), *a, **k)
+    assert plan((32, 2160, 3840, 3), torch.uint8, "bilinear", torch.uint8) == "rwh::warp_rgb8_fast8<unsigned char, 6>"
+    assert plan((2160, 3840, 3), torch.uint8, "bilinear", torch.float32) == "rwh::warp_rgb8_fast8<float, 6>"
+    assert plan((2160, 3840, 3), torch.uint8, "nn", torch.uint8) == "rwh::warp_rgb8_nn<6>"
+    assert plan((2160, 3840, 3), torch.uint8, "bilinear", torch.float64, exact=True) == "rwh::warp_exact<unsigned char, 3, double, 1>"
+    assert plan((2160, 3840, 4), torch.float32, "bilinear", torch.float32) == "rwh::warp_generic<float, 4, float, 1>"
+    assert kernels.warp_plan((4, 2160, 3840, 3), torch.uint8, np.stack([inv] * 4), g, (2160, 3840), "bilinear",
+                             torch.uint8) == "rwh::warp_rgb8_fast8_tab<unsigned char, 6>"
+    # the shape is a function of the homography and the whole grid, never of the row shard
+    assert plan((2160, 3840, 3), torch.uint8, "bilinear", torch.uint8, rows=(500, 700)) == "rwh::warp_rgb8_fast8<unsigned char, 6>"
+    # a 30-degree rotation leaves the 64 x 8 window: 32 x 16 patches; an output narrower than 128 px: the 4 px kernel
+    t = np.deg2rad(30)
+    R = np.array([[np.cos(t), -np.sin(t), 100.0], [np.sin(t), np.cos(t), -50.0], [0, 0, 1.0]])
+    assert kernels.warp_plan((2160, 3840, 3), torch.uint8, np.linalg.inv(R), g, (2160, 3840), "bilinear",
+                             torch.uint8) == "rwh::warp_rgb8_fast8<unsigned char, 5>"
+    assert kernels.warp_plan((100, 100, 3), torch.uint8, inv, kernels.Grid(0, 99, 100, 0, 99, 100), (100, 100), "bilinear",
+                             torch.uint8) == "rwh::warp_rgb8_fast<unsigned char>"
+
+
 def test_no_cpu_fallback():
     import torch
     if torch.cuda.is_available():
