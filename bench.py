@@ -354,6 +354,21 @@ def _other_kernels_leg(backend, src_w, src_h, nb):
                        "mpix_per_s": round(nb * out_h * out_w / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "frames": nb,
                        "achieved_GBps": round(byt / ms / 1e6, 1), "frac_of_hbm_peak": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
         del d2
+    # 4-channel images (the reference's RGBA = float32 with the alpha plane of addAlpha; uint8 RGBA for completeness): the
+    # generic gather kernel -- 16-byte float32 texels gather well, there is no staged kernel for them
+    nb4 = min(nb, 8)
+    for name, sdt in (("rgba_f32_bilinear", torch.float32), ("rgba_u8_bilinear", torch.uint8)):
+        s4 = (torch.rand((nb4, src_h, src_w, 4), device=backend.dev) * 255).to(sdt)
+        d4 = torch.empty((nb4, out_h, out_w, 4), dtype=sdt, device=backend.dev)
+
+        def step4():
+            k.warp_backward(s4, inv, grid, (src_h, src_w), "bilinear", sdt, zero_origin=False, out=d4)
+        _, ms = timed(backend, step4, 10, 5, backend.sync)
+        byt = nb4 * 4 * s4.element_size() * (src_h * src_w + out_h * out_w)
+        other[name] = {"kernel": k.warp_plan((nb4, src_h, src_w, 4), sdt, inv, grid, (src_h, src_w), "bilinear", sdt),
+                       "mpix_per_s": round(nb4 * out_h * out_w / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "frames": nb4,
+                       "achieved_GBps": round(byt / ms / 1e6, 1), "frac_of_hbm_peak": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        del s4, d4
     return other
 
 
