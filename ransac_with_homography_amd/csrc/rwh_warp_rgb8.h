@@ -508,7 +508,7 @@ __device__ __forceinline__ void comp_store(const CompArgs& c, const float (&o)[F
 //   LOG_PW = 5    32 x 16 patches, 4 side by side            -- any rotation at scale ~1
 //
 // Staging (round 2): the footprint window of a patch shape is FIXED -- F8_LPRW<LOG_PW> chunks (12 bytes = 4 texels)
-// wide, F8_SLAB / (16 * F8_LPRW) rows tall -- and so is the staging lane map: lane l serves chunk l % LPRW of row l / LPRW of
+// wide, F8Window::ROWS rows tall -- and so is the staging lane map: lane l serves chunk l % LPRW of row l / LPRW of
 // each pass, RPP = 64 / LPRW rows per pass.  Source address = scalar row-group base + a per-lane offset computed once,
 // slab address = a per-lane offset computed once + a scalar: a pass is one 12-byte load, the RGB -> RGBX expansion
 // (4 VALU) and one 16-byte LDS write.  (Round 1 let the footprint be any `nrows x C` area and derived row / column of
@@ -516,23 +516,24 @@ __device__ __forceinline__ void comp_store(const CompArgs& c, const float (&o)[F
 // arithmetic, now 28 -- profiles/r02_isa_histogram.txt.)  The host picks the shape whose window fits (launch_fast); a
 // wave whose footprint does not fit takes the gather path, so the choice only affects speed, never the result.
 //
-//   LOG_PW   patch     window (texels x rows)   rows per pass     slab
-//     7     128 x 4        168 x 7                  1  (42 lanes)    4704 B
-//     6      64 x 8         84 x 15                 3  (63 lanes)    5040 B
-//     5      32 x 16        40 x 31                 6  (60 lanes)    4960 B
-// (<= 5040 B per wave = 20 160 B per block: 8 blocks per CU fit the 160 KB of LDS)
+//   LOG_PW   patch     window (texels x rows)   rows per pass     slab per wave   waves per SIMD (uint8 out)
+//     7     128 x 4        168 x 7                  1  (42 lanes)    4704 B          7
+//     6      64 x 8         84 x 15                 3  (63 lanes)    5040 B          8   (20 160 B per block: 8 blocks per CU)
+//     5      32 x 16        40 x 38                 6  (60 lanes)    6080 B          6
+// 32 x 16 is the shape for rotations: a patch turned by any angle has a footprint of at most 38 x 38 texels
+// (sqrt(32^2 + 16^2) + 2), so its window is 38 rows tall -- at the price of two waves of occupancy.
 constexpr int F8_PX = 8;
-constexpr int F8_SLAB = 5040;                           // bytes of LDS per wave
 template <int LOG_PW> struct F8Window {
     static constexpr int LPRW = LOG_PW == 7 ? 42 : LOG_PW == 6 ? 21 : 10;   // chunks (staging lanes) per window row
     static constexpr int RPP = 64 / LPRW;                                   // window rows per staging pass
     static constexpr int LPITCH = 16 * LPRW;                                // slab bytes per window row
-    static constexpr int ROWS = F8_SLAB / LPITCH;                           // window rows
+    static constexpr int ROWS = LOG_PW == 7 ? 7 : LOG_PW == 6 ? 15 : 38;    // window rows
+    static constexpr int SLAB = ROWS * LPITCH;                              // bytes of LDS per wave
     static constexpr int PASSES = (ROWS + RPP - 1) / RPP;
 };
 inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // host + device twin of the `staged` test
-    const int lprw = log_pw == 7 ? 42 : log_pw == 6 ? 21 : 10;
-    return nrows >= 64 / lprw && nrows <= F8_SLAB / (16 * lprw) && ((ntex + 3) >> 2) <= lprw;
+    const int lprw = log_pw == 7 ? 42 : log_pw == 6 ? 21 : 10, rows = log_pw == 7 ? 7 : log_pw == 6 ? 15 : 38;
+    return nrows >= 64 / lprw && nrows <= rows && ((ntex + 3) >> 2) <= lprw;
 }
 
 #ifndef RWH_F8_WAVES
@@ -554,7 +555,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
     // float32 output: 3 KB more per wave, through which a run's pixels are re-dealt into coalesced 16-byte stores (blend_store)
     constexpr int XPOSE = sizeof(DstT) == 1 ? 0 : 3072;
-    constexpr int SLAB = F8_SLAB + XPOSE;
+    constexpr int SLAB = F8Window<LOG_PW>::SLAB + XPOSE;
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][SLAB];
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
@@ -762,7 +763,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             const int first = tshift - (lcol + (PW / 2) * h);   // local pixels at columns >= first are this tile's
             if constexpr (PSTR > 1) {
                 // float32 output: re-deal through the free upper half of the slab when there is one (uniform)
-                unsigned char* xp = tshift == 0 ? my + F8_SLAB : nullptr;
+                unsigned char* xp = tshift == 0 ? my + Win::SLAB : nullptr;
                 blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
                                         xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
             } else if constexpr (COMP) {
@@ -852,13 +853,13 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 }
 
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
 // canvas compositor form (uint8): the output grid is the canvas, imgQ is composited in the epilogue (CompArgs)
 template <int LOG_PW>
 __global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_comp(const FastArgs a, const CompArgs c) { fast8_body<unsigned char, LOG_PW, true>(a, nullptr, &c); }
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
@@ -906,7 +907,7 @@ template <int LOG_PW>
 __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW, LPR = PW / 8, WX = 128 / PW;
     constexpr double MAGIC_R = MAGIC + 0.5;                 // hi(s + MAGIC_R) - MAGIC_HI = floor(s + 0.5)
-    __shared__ __attribute__((aligned(16))) unsigned char slab[4][F8_SLAB];
+    __shared__ __attribute__((aligned(16))) unsigned char slab[4][F8Window<LOG_PW>::SLAB];
 
     const unsigned b = blockIdx.x;
     const unsigned logical = (b & 7u) * a.cpx + (b >> 3);
@@ -1029,7 +1030,7 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const uint32_t slab_off = (uint32_t)wave * (uint32_t)F8_SLAB;
+    const uint32_t slab_off = (uint32_t)wave * (uint32_t)Win::SLAB;
     const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {

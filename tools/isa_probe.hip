@@ -70,6 +70,59 @@ __global__ void k_glds(uint32_t* out, const uint32_t* src) {
     for (int i = threadIdx.x; i < 1024; i += 64) out[i] = lds[i];
 }
 
+// the same with a byte-misaligned global address (src + 16 l + mis): does the DMA path take it, and is it slower?
+__global__ void k_glds_mis(uint32_t* out, const unsigned char* src, int mis) {
+    __shared__ uint32_t lds[1024];
+    for (int i = threadIdx.x; i < 1024; i += 64) lds[i] = 0xdeadbeefu;
+    __syncthreads();
+    const unsigned char* p = src + 16 * threadIdx.x + mis;
+    const unsigned ldsbase = (unsigned)(uintptr_t)lds + 64;
+    asm volatile("s_mov_b32 m0, %1\n s_nop 0\n global_load_lds_dwordx4 %0, off\n s_waitcnt vmcnt(0)" :: "v"(p), "s"(ldsbase) : "memory", "m0");
+    __syncthreads();
+    for (int i = threadIdx.x; i < 1024; i += 64) out[i] = lds[i];
+}
+// throughput: every wave copies ROWS rows of 256 B (16 lanes x 16 B) global -> LDS, aligned or misaligned, DMA or through VGPRs
+template <int MODE>   // 0 = DMA aligned, 1 = DMA misaligned by 3, 2 = dwordx4 load + ds_write_b128 aligned, 3 = dwordx3 loads (12 B / lane, 21 lanes)
+__global__ __launch_bounds__(256) void k_stage(float* out, const unsigned char* src, size_t pitch, int iters) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[4][4096];
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+    // rows [base_row, base_row + 15 * 64 + 12) of a 34 560-row buffer: always inside it (the host allocates rows x pitch + 64 KB)
+    const size_t base_row = (((size_t)blockIdx.x * 4 + wave) * 16) % (34560 - 1024);
+    const unsigned char* base = src + base_row * pitch;
+    uint32_t acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        const unsigned char* g = base + (size_t)(it & 15) * pitch * 64;
+        if constexpr (MODE <= 1) {
+            if (lane < 16) {
+#pragma unroll
+                for (int r = 0; r < 12; ++r) {
+                    const unsigned char* p = g + r * pitch + 16 * lane + (MODE == 1 ? 3 : 0);
+                    const unsigned ldsb = (unsigned)__builtin_amdgcn_readfirstlane((int)((unsigned)(uintptr_t)(&lds[wave][0]) + r * 256));
+                    asm volatile("s_mov_b32 m0, %1\n s_nop 0\n global_load_lds_dwordx4 %0, off" :: "v"(p), "s"(ldsb) : "memory", "m0");
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if constexpr (MODE == 2) {
+            uint4 v[3];
+            const int row = lane >> 4, col = lane & 15;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) __builtin_memcpy(&v[r], g + (4 * r + row) * pitch + 16 * col, 16);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) *reinterpret_cast<uint4*>(&lds[wave][(4 * r + row) * 256 + 16 * col]) = v[r];
+        } else {
+            struct __attribute__((packed)) p3 { uint32_t a, b, c; } v[4];
+            const int row = lane / 21, col = lane % 21;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (row < 3) __builtin_memcpy(&v[r], g + (3 * r + row) * pitch + 12 * col + 3, 12);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) if (row < 3) { uint4 t = {v[r].a, v[r].b, v[r].c, 0u}; *reinterpret_cast<uint4*>(&lds[wave][(3 * r + row) * 336 + 16 * col]) = t; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        acc += *reinterpret_cast<uint32_t*>(&lds[wave][4 * lane]);
+    }
+    if (acc == 0x12345u) out[threadIdx.x] = (float)acc;
+}
+
 // ---------------------------------------------------------------- VALU rates ----
 #define KERNEL(NAME, DECL, BODY, SINK)                                              \
     __global__ __launch_bounds__(256) void NAME(float* out, float seed) {          \
@@ -237,6 +290,33 @@ int main() {
     printf("  global_load_lds_dwordx4: dwords written %d..%d (want 16..271), contiguous lane-major copy: %s\n", first, last, inorder ? "yes" : "NO");
     if (!inorder && first >= 0) { printf("   first 12 dwords:"); for (int i = first; i < first + 12; ++i) printf(" %x", hl[i]); printf("\n"); }
 
+    {
+        unsigned char* big; const size_t pitch = 11520, nbytes = pitch * 34560 + 65536;
+        CK(hipMalloc(&big, nbytes)); CK(hipMemset(big, 7, nbytes));
+        for (int mis = 1; mis <= 3; mis += 2) {
+            hipLaunchKernelGGL(k_glds_mis, dim3(1), dim3(64), 0, 0, dout32, reinterpret_cast<const unsigned char*>(din), mis);
+            CK(hipMemcpy(hl, dout32, sizeof hl, hipMemcpyDeviceToHost));
+            int ok = 1;
+            const unsigned char* hb = reinterpret_cast<const unsigned char*>(hin);
+            const unsigned char* lb = reinterpret_cast<const unsigned char*>(hl);
+            for (int i = 0; i < 1024 - mis - 64; ++i) if (lb[64 + i] != hb[i + mis]) { ok = 0; break; }
+            printf("  global_load_lds_dwordx4 from a global address misaligned by %d: %s\n", mis, ok ? "bytes land in order" : "WRONG / not supported");
+        }
+        hipEvent_t a0, a1; CK(hipEventCreate(&a0)); CK(hipEventCreate(&a1));
+        const char* names[4] = {"DMA dwordx4 aligned (16 lanes x 12 rows)", "DMA dwordx4 misaligned by 3", "dwordx4 loads + ds_write_b128 (64 lanes x 3)", "dwordx3 loads misaligned + ds_write_b128 (63 lanes x 4)"};
+        void (*ks[4])(float*, const unsigned char*, size_t, int) = {k_stage<0>, k_stage<1>, k_stage<2>, k_stage<3>};
+        for (int m = 0; m < 4; ++m) {
+            const int blocks = 2048, iters = 64;
+            hipLaunchKernelGGL(ks[m], dim3(blocks), dim3(256), 0, 0, out, big, pitch, iters);
+            CK(hipEventRecord(a0));
+            hipLaunchKernelGGL(ks[m], dim3(blocks), dim3(256), 0, 0, out, big, pitch, iters);
+            CK(hipEventRecord(a1)); CK(hipEventSynchronize(a1));
+            float ms; CK(hipEventElapsedTime(&ms, a0, a1));
+            const double bytes = (double)blocks * 4 * iters * 12 * 256;
+            printf("  staging %-58s %.3f ms  %.0f GB/s into LDS\n", names[m], ms, bytes / ms / 1e6);
+        }
+        CK(hipFree(big));
+    }
     Case cases[] = {
         {"v_fma_f32", k_fma_f32, 8}, {"v_add_f32", k_add_f32, 8}, {"v_add_u32", k_add_u32, 8}, {"v_pk_fma_f32", k_pk_fma_f32, 8}, {"v_pk_mul_f32", k_pk_mul_f32, 8},
         {"v_fma_mix_f32 (lo)", k_fma_mix, 8}, {"v_fma_mix_f32 (hi)", k_fma_mix_hi, 8}, {"v_dot2_f32_f16", k_dot2_f32_f16, 8},

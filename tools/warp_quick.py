@@ -6,12 +6,17 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_with_homography_amd import _lib, kernels
 from ransac_with_homography_amd import homography as hg
 H_S = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+if "ROT" in os.environ or "SCALE" in os.environ:      # rotation by ROT degrees / zoom by SCALE about the image centre instead
+    t, sc = np.deg2rad(float(os.environ.get("ROT", "0"))), float(os.environ.get("SCALE", "1"))
+    W0, H0 = (int(v) for v in os.environ.get("SRC", "3840x2160").split("x"))
+    c, s_ = np.cos(t) * sc, np.sin(t) * sc
+    H_S = np.array([[c, -s_, W0 / 2 - c * W0 / 2 + s_ * H0 / 2], [s_, c, H0 / 2 - s_ * W0 / 2 - c * H0 / 2], [0, 0, 1.0]])
 frames = int(os.environ.get("FRAMES", "32"))
 W, Hh = (int(v) for v in os.environ.get("SRC", "3840x2160").split("x"))
 dev = _lib.require_gpu()
 g = torch.Generator(device="cpu").manual_seed(1)
 src = torch.randint(0, 256, (frames, Hh, W, 3), dtype=torch.uint8, generator=g).to(dev)
-mx, my, ow, oh = hg._bounds(Hh, W, H_S, 0)
+mx, my, ow, oh = (0, 0, W, Hh) if ("ROT" in os.environ or "SCALE" in os.environ) else hg._bounds(Hh, W, H_S, 0)
 grid = kernels.Grid(mx, mx + ow - 1, ow, my, my + oh - 1, oh)
 inv = np.linalg.inv(H_S)
 out = torch.empty((frames, oh, ow, 3), dtype=torch.uint8, device=dev)
@@ -30,4 +35,6 @@ for kind in [int(a) for a in sys.argv[1:]] or [6, 22, 23]:
     by = frames * (Hh * W * 3 + oh * ow * 3)
     same = "" if ref is None else (" identical to first kind: %s" % bool(torch.equal(ref, out)))
     if ref is None: ref = out.clone()
+    plan = kernels.warp_plan((frames, Hh, W, 3), torch.uint8, inv, grid, (Hh, W), "bilinear", torch.uint8)
+    print(plan, end="  ")
     print("kind %2d  %.4f ms per %d frames = %.2f us/frame  %.0f GB/s = %.3f of 8 TB/s%s" % (kind, ms, frames, ms * 1e3 / frames, by / ms / 1e6, by / ms / 1e6 / 8000, same), flush=True)
