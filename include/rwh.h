@@ -241,7 +241,9 @@ RWH_API int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, const
  * d_img_t: imgT (t_h x t_w x 3 uint8, the image warped by H); d_img_q: imgQ (q_h x q_w x 3 uint8).
  * inv_h: inv(H); (grid_x0, grid_y0, warp_w, warp_h): wrapPerspective's output grid (min_x, min_y, max_w, max_h);
  * (tsx, tsy) / (qsx, qsy): where the warped imgT / imgQ sit on the canvas_h x canvas_w canvas.
- * blend == 0: paste imgQ over the warped imgT; blend != 0: the 'Rate' alpha blend with blendrate `rate`.
+ * blend == 0: paste imgQ over the warped imgT; 1: the 'Rate' alpha blend with blendrate `rate`; 2: the 'Gradient' blend
+ * (alpha of imgT = the (x + y) / (w + h) / 2 ramp of homography.py:260-265, alpha of imgQ = 1; always the exact kernel).
+ * Any other value: RWH_E_INVALID.
  * flags: RWH_WARP_ZERO_ORIGIN blanks texel (0,0) of imgT first, as bilinear() does to the caller's array;
  * RWH_STITCH_FAST: the staged float32-blend warp kernel with the compositor as its epilogue (rwh::warp_rgb8_comp) instead of
  * the float64 one-pixel-per-thread kernel: ~4x faster, canvas within 1 LSB of the reference's (the alpha plane's own

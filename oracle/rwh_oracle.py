@@ -249,6 +249,17 @@ def add_alpha_rate(img, rate=0.2):
     return out
 
 
+def add_alpha_gradient(img):
+    """homography.py:250-266, method 'Gradient', direction LEFT, alphaOnly False:
+    the alpha plane is the float64 ramp (x + y) / (w + h) * 0.5 stored as float32."""
+    h, w, c = img.shape
+    out = np.zeros((h, w, c + 1), dtype=np.float32)
+    out[:, :, :c] = img
+    xx, yy = np.meshgrid(np.linspace(0, w - 1, w), np.linspace(0, h - 1, h))
+    out[:, :, c] = (xx + yy) / (w + h) * 0.5
+    return out
+
+
 def stitch_geometry(wt, ht, wq, hq, mx, my):
     """Canvas geometry of homography.py:303-321.  Returns the inclusive paste
     rectangles (tsx,tsy,tex,tey) for the warped image, (qsx,qsy,qex,qey) for
@@ -272,9 +283,11 @@ def stitch_geometry(wt, ht, wq, hq, mx, my):
 
 def stitch_panorama(imgQ, imgT, H, blending=False, blendrate=0.2):
     """homography.py:288-338.  Warp imgT by H (always bilinear), place it and
-    imgQ on a common canvas; 'Rate' blending alpha-averages the overlap in
-    float32, otherwise imgQ is pasted over the warped imgT."""
-    if blending:
+    imgQ on a common canvas; 'Rate' / 'Gradient' blending alpha-averages the
+    overlap in float32, otherwise imgQ is pasted over the warped imgT."""
+    if blending == 'Gradient':
+        imgT = add_alpha_gradient(imgT)
+    elif blending:
         imgT = add_alpha_rate(imgT, blendrate)
     img_t, mx, my = transform_image_h(imgT, H)
     ht, wt, ct = img_t.shape

@@ -1,5 +1,5 @@
 // Fused panorama compositor: replaces, in ONE pass over the canvas,
-//   addAlpha(imgT, 'Rate', rate)                                 homography.py:250-258
+//   addAlpha(imgT, 'Rate' | 'Gradient', rate)                    homography.py:250-266
 //   transformImageH(imgT[, alpha]) -> wrapPerspective + bilinear  homography.py:230-242, 142-184, 123-138
 //   the canvas paste / alpha blend of stitchPanorama             homography.py:322-338
 // Nothing is materialised: no H x W x 4 float32 alpha image, no float64 warped RGBA, no float32 canvas.
@@ -24,8 +24,9 @@ struct StitchArgs {
     int tsx, tsy, wt, ht;         // warped-T rectangle on the canvas and its size (= the warp's output grid)
     int gx0, gy0;                 // warp grid origin (min_x, min_y): output pixel (c, r) of the warp is at (gx0 + c, gy0 + r)
     int qsx, qsy;                 // imgQ rectangle origin on the canvas
-    int blend;                    // 0 = paste (imgQ over warped imgT), 1 = alpha blend
-    float alpha_t;                // float32(rate + 1e-10): alpha plane of imgT
+    int blend;                    // 0 = paste (imgQ over warped imgT), 1 = 'Rate' alpha blend, 2 = 'Gradient' alpha blend
+    float alpha_t;                // 'Rate': float32(rate + 1e-10), the constant alpha plane of imgT
+    double ramp_den;              // 'Gradient': w + h of imgT; alpha(x, y) = float32((x + y) / (w + h) * 0.5)
     float alpha_q_in, alpha_q_out;  // canvas alpha inside / outside the imgQ rectangle (float32)
 };
 
@@ -71,11 +72,17 @@ __global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
                 const double bot = u8(p10 + k) * gx + u8(p11 + k) * fx;
                 t_rgb[k] = top * gy + bot * fy;
             }
-            if (a.blend) {   // the alpha plane is constant except texel (0,0), which bilinear() blanks
-                const double A = (double)a.alpha_t;
-                const double a00 = (ix | iy) == 0 ? 0.0 : A, a01 = (ix1 | iy) == 0 ? 0.0 : A;
-                const double a10 = (ix | iy1) == 0 ? 0.0 : A, a11 = (ix1 | iy1) == 0 ? 0.0 : A;
-                const double top = a00 * gx + a01 * fx, bot = a10 * gx + a11 * fx;
+            if (a.blend) {
+                // the alpha plane is never read from memory: 'Rate' is a constant, 'Gradient' the float32 ramp of
+                // homography.py:260-265 (linspace gives exact integers; float64 divide, * 0.5, stored as float32);
+                // texel (0,0) is the one bilinear() blanks (the ramp is 0 there anyway)
+                const double A = (double)a.alpha_t, den = a.ramp_den;
+                const bool ramp = a.blend == 2;
+                auto tap = [&](int x, int y) -> double {
+                    if ((x | y) == 0) return 0.0;
+                    return ramp ? (double)(float)(((double)x + (double)y) / den * 0.5) : A;
+                };
+                const double top = tap(ix, iy) * gx + tap(ix1, iy) * fx, bot = tap(ix, iy1) * gx + tap(ix1, iy1) * fx;
                 t_a = top * gy + bot * fy;
             }
         }
@@ -113,7 +120,8 @@ extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const 
     if (flags & RWH_WARP_ZERO_ORIGIN) {
         if (hipMemsetAsync(const_cast<void*>(d_img_t), 0, 3, s) != hipSuccess) return RWH_E_LAUNCH;
     }
-    if (flags & RWH_STITCH_FAST) {
+    if (blend < 0 || blend > 2) return RWH_E_INVALID;
+    if ((flags & RWH_STITCH_FAST) && blend != 2) {   // the staged compositor carries constant weights: no ramp
         // the reference's float32 alphas (see below), then the two weight pairs of the mean in float64 -> float32
         const double ta = (double)(float)(rate + 1e-10), qa_in = (double)(float)(1 + 1e-10 - rate), qa_out = (double)(float)1e-10;
         CompArgs c;
@@ -133,10 +141,12 @@ extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const 
     for (int i = 0; i < 9; ++i) a.ih[i] = inv_h[i];
     a.t_h = t_h; a.t_w = t_w; a.q_h = q_h; a.q_w = q_w; a.fh = canvas_h; a.fw = canvas_w;
     a.tsx = tsx; a.tsy = tsy; a.wt = warp_w; a.ht = warp_h; a.gx0 = grid_x0; a.gy0 = grid_y0; a.qsx = qsx; a.qsy = qsy;
-    a.blend = blend ? 1 : 0;
+    a.blend = blend;
+    a.ramp_den = (double)(t_w + t_h);
     // the reference's Python-float arithmetic, then the float32 storage of its arrays
     a.alpha_t = (float)(rate + 1e-10);                 // addAlpha: rate += 1e-10; imgn[:, :, c] = rate   (float32 array)
-    a.alpha_q_in = (float)(1 + 1e-10 - rate);          // imgn[q-rect, 3] = 1 + 1e-10 - blendrate            (float32 array)
+    a.alpha_q_in = blend == 2 ? 1.0f                   // imgn[q-rect, 3] = 1                                 (homography.py:329)
+                              : (float)(1 + 1e-10 - rate);   // imgn[q-rect, 3] = 1 + 1e-10 - blendrate       (float32 array)
     a.alpha_q_out = (float)1e-10;                      // imgn[:, :, 3] += 1e-10 on a float32 zero
     const dim3 grid((canvas_w + 63) / 64, (canvas_h + 3) / 4), block(256);
     hipLaunchKernelGGL(stitch_kernel, grid, block, 0, s, a);

@@ -368,7 +368,8 @@ def _stitch_geometry(wt, ht, wq, hq, mx, my):
 
 def _stitch_host(imgQ, imgT, H, blending, blendrate):
     """stitchPanorama with the compositor on the host (homography.py:296-338 verbatim in structure): used for the
-    blending modes the fused kernel does not cover (anything truthy other than 'Rate') and for non-uint8 images."""
+    blending values the fused kernel does not cover (anything truthy other than 'Rate' / 'Gradient', for which the
+    reference builds an all-zero alpha plane) and for non-uint8 images."""
     if blending:
         imgT = addAlpha(imgT, method=blending, rate=blendrate)
     img_t, mx, my = transformImageH(imgT, H)
@@ -397,13 +398,14 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     """Warp imgT by H and composite it with imgQ on a common canvas (homography.py:288-338).  `method` is ignored
     exactly as in the reference (always bilinear).
 
-    uint8 RGB images with blending False or 'Rate' run in ONE fused kernel (`rwh_stitch_panorama`): alpha plane,
+    uint8 RGB images with blending False, 'Rate' or 'Gradient' run in ONE fused kernel (`rwh_stitch_panorama`): alpha plane,
     warp, paste / alpha blend per canvas pixel; nothing intermediate (RGBA float32 image, float64 warp, float32 canvas)
     is materialised.  numpy arrays in (or EXACT = True): the reference's float64 arithmetic, canvas bit-identical to the
     reference's; torch tensors in (or EXACT = False): the staged fast warp kernel with the compositor as its epilogue,
     canvas within 1 LSB."""
     import torch
-    fused = (blending is False or blending is None or blending == 0 or blending == 'Rate')
+    paste = blending is False or blending is None or blending == 0
+    fused = paste or blending in ('Rate', 'Gradient')
     tens = _is_tensor(imgQ) or _is_tensor(imgT)
     if not tens:
         fused = fused and np.asarray(imgQ).dtype == np.uint8 and np.asarray(imgT).dtype == np.uint8
@@ -412,8 +414,10 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     fused = fused and imgQ.shape[2] == 3 and imgT.shape[2] == 3
     if not fused:
         return _stitch_host(imgQ, imgT, H, blending, blendrate)
-    if blending:
+    if blending == 'Rate':
         print(blendrate + 1e-10)   # addAlpha prints the rate it stores (homography.py:257)
+    elif blending == 'Gradient':
+        print('not implement yet')  # homography.py:266
     h, w, _ = imgT.shape
     mx, my, wt, ht = _bounds(h, w, H, 0)
     if wt <= 0 or ht <= 0:
@@ -431,8 +435,9 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
         t_dev = torch.from_numpy(np.ascontiguousarray(imgT)).to(dev)
         q_dev = torch.from_numpy(np.ascontiguousarray(imgQ)).to(dev)
     exact = (not tens) if EXACT is None else bool(EXACT)    # numpy in: the bit-identical float64 kernel; tensors in: the fast one
+    mode = 0 if paste else 1 if blending == 'Rate' else 2   # 'Gradient': the alpha ramp, exact kernel only
     out = kernels.stitch_panorama(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), (fh, fw),
-                                  bool(blending), blendrate, zero_origin=True, fast=not exact)
+                                  mode, blendrate, zero_origin=True, fast=not exact)
     if tens:
         return out
     if not blending:

@@ -237,7 +237,8 @@ def project_points_ex(h9, pts3):
 
 def stitch_panorama(img_t, img_q, inv_h, grid_origin, warp_wh, t_origin, q_origin, canvas_hw, blend, rate, zero_origin=True, fast=False):
     """Launch the fused compositor: img_t / img_q [H,W,3] uint8 GPU tensors -> canvas [fh,fw,3] uint8.  fast=True: the
-    staged warp kernel with the compositor epilogue (within 1 LSB); False: the exact float64 kernel (bit-identical)."""
+    staged warp kernel with the compositor epilogue (within 1 LSB); False: the exact float64 kernel (bit-identical).
+    blend: 0 / False paste, 1 / True 'Rate', 2 'Gradient' (exact kernel only)."""
     lib = _lib.load()
     _dev_check(img_t, img_q)
     assert img_t.dtype == torch.uint8 and img_q.dtype == torch.uint8 and img_t.shape[2] == 3 and img_q.shape[2] == 3
@@ -247,7 +248,7 @@ def stitch_panorama(img_t, img_q, inv_h, grid_origin, warp_wh, t_origin, q_origi
     check(lib.rwh_stitch_panorama(_ptr(img_t), img_t.shape[0], img_t.shape[1], _ptr(img_q), img_q.shape[0], img_q.shape[1],
                                   ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(grid_origin[0]), int(grid_origin[1]),
                                   int(warp_wh[0]), int(warp_wh[1]), int(t_origin[0]), int(t_origin[1]), int(q_origin[0]),
-                                  int(q_origin[1]), int(fh), int(fw), 1 if blend else 0, float(rate), _ptr(out),
+                                  int(q_origin[1]), int(fh), int(fw), int(blend), float(rate), _ptr(out),
                                   (RWH_WARP_ZERO_ORIGIN if zero_origin else 0) | (_lib.RWH_STITCH_FAST if fast else 0),
                                   _lib.stream_ptr()), "rwh_stitch_panorama")
     return out

@@ -323,8 +323,22 @@ def g8():
     save("img_foto1", A=A, B=B)
 
 
+def g11():
+    """'Gradient' blending (homography.py:259-266, 327-334): the alpha ramp the reference leaves half finished but runs."""
+    rng = np.random.default_rng(11)
+    A = decode("foto1A.jpg")
+    B = decode("foto1B.jpg")
+    H5 = np.load(os.path.join(OUT, "g8_stitch.npz"))["H_g5"]
+    out = {}
+    o = ref_h.stitchPanorama(B.copy(), A.copy(), H_NOTEBOOK, blending="Gradient")
+    out.update(digest("stitch_gradient", o, rng))
+    o = ref_h.stitchPanorama(B.copy(), A.copy(), H5, blending="Gradient")
+    out.update(digest("stitch_g5_gradient", o, rng))
+    save("g11_stitch_gradient", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -335,6 +349,7 @@ def main():
     if "g8" in which: g8()
     if "g9" in which: g9(ptsA, ptsB)
     if "g10" in which: g10(ptsA, ptsB)
+    if "g11" in which: g11()
 
 
 if __name__ == "__main__":

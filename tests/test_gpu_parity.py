@@ -1215,6 +1215,13 @@ def test_exact_mode_photo_goldens_sha256(gpu, exact_mode):
     assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"])) == str(z["stitch_paste_sha256"])
     assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"], blending="Rate", blendrate=0.2)) == str(z["stitch_rate_sha256"])
     assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_g5"], blending="Rate", blendrate=0.2)) == str(z["stitch_g5_rate_sha256"])
+    # 'Gradient' (homography.py:259-266): the alpha ramp is synthesised per tap in the fused kernel, for numpy and tensor callers
+    zg = load_golden("g11_stitch_gradient")
+    assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_notebook"], blending="Gradient")) == str(zg["stitch_gradient_sha256"])
+    assert _sha(hg.stitchPanorama(f["B"].copy(), f["A"].copy(), z["H_g5"], blending="Gradient")) == str(zg["stitch_g5_gradient_sha256"])
+    At, Bt = torch.from_numpy(f["A"]).to(gpu), torch.from_numpy(f["B"]).to(gpu)
+    assert _sha(hg.stitchPanorama(Bt, At, z["H_g5"], blending="Gradient").cpu().numpy()) == str(zg["stitch_g5_gradient_sha256"])
+    assert int(At[0, 0].sum()) == int(f["A"][0, 0].sum())     # addAlpha copies: the caller's texel (0,0) survives
 
 
 def test_entry_points_are_graph_capturable(gpu):

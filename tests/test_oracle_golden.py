@@ -158,3 +158,6 @@ def test_g8_stitch():
     o = orc.stitch_panorama(B.copy(), A.copy(), z["H_g5"], blending="Rate", blendrate=0.2)
     assert o.shape == (788, 1647, 3)
     check_digest(z, "stitch_g5_rate", o)
+    z = load_golden("g11_stitch_gradient")      # the alpha ramp of homography.py:259-266
+    check_digest(z, "stitch_gradient", orc.stitch_panorama(B.copy(), A.copy(), load_golden("g8_stitch")["H_notebook"], blending="Gradient"))
+    check_digest(z, "stitch_g5_gradient", orc.stitch_panorama(B.copy(), A.copy(), load_golden("g8_stitch")["H_g5"], blending="Gradient"))
