@@ -46,7 +46,10 @@ struct WarpArgs {
     unsigned tiles_x, tiles_y, nblocks, cpx;
 };
 
-constexpr int PX = 4;        // pixels per lane
+constexpr int PX = 4;        // pixels per lane (uint8 output: 12 / 16 bytes per lane and store)
+// float32 output is 12 / 16 bytes per PIXEL already: one pixel per lane, so that a wave's taps go out together, a wave
+// stores 64 consecutive pixels with one instruction, and four times as many waves are there to hide the gathers
+template <typename DstT, int C> constexpr int generic_px() { return sizeof(DstT) == 1 ? PX : 1; }   // (uint8 RGBA at 1 px per lane: 23 % slower)
 constexpr int TILE_ROWS = 4; // waves per block, one output row each
 
 template <typename T> struct elem;
@@ -131,6 +134,7 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
     const int rr = (int)ty * TILE_ROWS + wrow;
     if (rr >= a.rows) return;
     const int r = a.row_begin + rr;
+    constexpr int PX = generic_px<DstT, C>();
     const int c0 = ((int)tx * RWH_WAVE + lane) * PX;
     if (c0 >= a.out_w) return;
 
@@ -175,6 +179,8 @@ __global__ __launch_bounds__(256) void warp_generic(const WarpArgs a) {
                 const float wy1 = (float)fy, wy0 = (float)(1.0 - fy);
                 const int ix1 = min(ix + 1, a.src_w - 1), iy1 = min(iy + 1, a.src_h - 1);
                 float p00[C], p01[C], p10[C], p11[C];
+                // (one 8-byte load per tap PAIR of a uint8 source was tried: 20 % slower -- the kernel is bound by its
+                //  per-pixel float64 arithmetic, ~200 Gpix/s whatever the format, not by the gathers)
                 load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy, ix, p00);
                 load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy, ix1, p01);
                 load_texel<SrcT, C>(simg, img_bytes, a.src_w, iy1, ix, p10);
@@ -346,14 +352,39 @@ int launch(K kernel, const WarpArgs& a, hipStream_t s, const char* family, const
     return check_launch();
 }
 
+// the block grid for `px` pixels per lane (the entry point sets it up for PX); false: too many blocks for one launch
+static bool retile(WarpArgs& a, int px) {
+    const unsigned long long per_img = (unsigned long long)a.tiles_x * a.tiles_y;
+    const unsigned long long batch = per_img ? a.nblocks / per_img : 0;
+    a.tiles_x = (unsigned)((a.out_w + RWH_WAVE * px - 1) / (RWH_WAVE * px));
+    const unsigned long long nb = (unsigned long long)a.tiles_x * a.tiles_y * batch;
+    if (nb >= (1ull << 31) / 8) return false;
+    a.nblocks = (unsigned)nb;
+    a.cpx = (a.nblocks + 7u) / 8u;
+    return true;
+}
+
 template <typename SrcT, int C>
 int dispatch(const WarpArgs& a, int interp, int dst_dtype, hipStream_t s) {
     if (interp == RWH_NEAREST) {
         if (dst_dtype != elem<SrcT>::dtype) return RWH_E_UNSUPPORTED;
+        if constexpr (generic_px<SrcT, C>() != PX) {
+            WarpArgs b = a;
+            if (!retile(b, generic_px<SrcT, C>())) return RWH_E_UNSUPPORTED;
+            return launch(warp_generic<SrcT, C, SrcT, RWH_NEAREST>, b, s, "warp_generic", tname<SrcT>(), C, tname<SrcT>(), RWH_NEAREST);
+        }
         return launch(warp_generic<SrcT, C, SrcT, RWH_NEAREST>, a, s, "warp_generic", tname<SrcT>(), C, tname<SrcT>(), RWH_NEAREST);
     }
-    if (dst_dtype == RWH_F32) return launch(warp_generic<SrcT, C, float, RWH_BILINEAR>, a, s, "warp_generic", tname<SrcT>(), C, "float", RWH_BILINEAR);
-    if (dst_dtype == RWH_U8) return launch(warp_generic<SrcT, C, unsigned char, RWH_BILINEAR>, a, s, "warp_generic", tname<SrcT>(), C, "unsigned char", RWH_BILINEAR);
+    if (dst_dtype == RWH_F32) {
+        WarpArgs b = a;
+        if (!retile(b, generic_px<float, C>())) return RWH_E_UNSUPPORTED;
+        return launch(warp_generic<SrcT, C, float, RWH_BILINEAR>, b, s, "warp_generic", tname<SrcT>(), C, "float", RWH_BILINEAR);
+    }
+    if (dst_dtype == RWH_U8) {
+        WarpArgs b = a;
+        if (!retile(b, generic_px<unsigned char, C>())) return RWH_E_UNSUPPORTED;
+        return launch(warp_generic<SrcT, C, unsigned char, RWH_BILINEAR>, b, s, "warp_generic", tname<SrcT>(), C, "unsigned char", RWH_BILINEAR);
+    }
     return RWH_E_UNSUPPORTED;
 }
 
