@@ -30,24 +30,23 @@ struct StitchArgs {
     float alpha_q_in, alpha_q_out;  // canvas alpha inside / outside the imgQ rectangle (float32)
 };
 
-__device__ __forceinline__ double u8(const unsigned char* p) { return (double)*p; }
+// One RGB texel as a dword: an unaligned 4-byte load (3 bytes used) unless that would step past the image's last byte.
+__device__ __forceinline__ uint32_t rgb_at(const unsigned char* base, size_t off, size_t img_bytes) {
+    if (off + 4 <= img_bytes) return ld4(base + off);
+    return (uint32_t)base[off] | ((uint32_t)base[off + 1] << 8) | ((uint32_t)base[off + 2] << 16);
+}
+__device__ __forceinline__ double chan(uint32_t texel, int k) { return (double)((texel >> (8 * k)) & 0xffu); }
 
-__global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
-    const int cx = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cx >= a.fw || cy >= a.fh) return;
-    unsigned char* out = a.dst + ((size_t)cy * a.fw + cx) * 3;
-
+// One canvas pixel, the reference's arithmetic operation by operation; returns the pixel as 0x00BBGGRR.
+template <bool BLEND>
+__device__ __forceinline__ uint32_t stitch_pixel(const StitchArgs& a, int cx, int cy, size_t t_bytes, size_t q_bytes) {
     const int qx = cx - a.qsx, qy = cy - a.qsy;
     const bool in_q = (qx >= 0) & (qx < a.q_w) & (qy >= 0) & (qy < a.q_h);
-    const unsigned char* q = a.src_q + ((size_t)(in_q ? qy : 0) * a.q_w + (in_q ? qx : 0)) * 3;
+    const uint32_t q = in_q ? rgb_at(a.src_q, ((size_t)qy * a.q_w + qx) * 3, q_bytes) & 0xFFFFFFu : 0u;
     const int tx = cx - a.tsx, ty = cy - a.tsy;
     const bool in_t = (tx >= 0) & (tx < a.wt) & (ty >= 0) & (ty < a.ht);
+    if (!BLEND && in_q) return q;    // paste: imgQ is written last (homography.py:337-338)
 
-    if (!a.blend && in_q) {          // paste: imgQ is written last (homography.py:337-338)
-        out[0] = q[0]; out[1] = q[1]; out[2] = q[2];
-        return;
-    }
     double t_rgb[3] = {0.0, 0.0, 0.0}, t_a = 0.0;
     if (in_t) {
         // warp_exact's coordinate recipe: dgemm k-order, IEEE divides
@@ -62,17 +61,17 @@ __global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
             const double fx = sx - (double)ix, fy = sy - (double)iy;
             const double gx = 1.0 - fx, gy = 1.0 - fy;
             const int ix1 = min(ix + 1, a.t_w - 1), iy1 = min(iy + 1, a.t_h - 1);
-            const unsigned char* p00 = a.src_t + ((size_t)iy * a.t_w + ix) * 3;
-            const unsigned char* p01 = a.src_t + ((size_t)iy * a.t_w + ix1) * 3;
-            const unsigned char* p10 = a.src_t + ((size_t)iy1 * a.t_w + ix) * 3;
-            const unsigned char* p11 = a.src_t + ((size_t)iy1 * a.t_w + ix1) * 3;
+            const uint32_t p00 = rgb_at(a.src_t, ((size_t)iy * a.t_w + ix) * 3, t_bytes);
+            const uint32_t p01 = rgb_at(a.src_t, ((size_t)iy * a.t_w + ix1) * 3, t_bytes);
+            const uint32_t p10 = rgb_at(a.src_t, ((size_t)iy1 * a.t_w + ix) * 3, t_bytes);
+            const uint32_t p11 = rgb_at(a.src_t, ((size_t)iy1 * a.t_w + ix1) * 3, t_bytes);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                const double top = u8(p00 + k) * gx + u8(p01 + k) * fx;
-                const double bot = u8(p10 + k) * gx + u8(p11 + k) * fx;
+                const double top = chan(p00, k) * gx + chan(p01, k) * fx;
+                const double bot = chan(p10, k) * gx + chan(p11, k) * fx;
                 t_rgb[k] = top * gy + bot * fy;
             }
-            if (a.blend) {
+            if constexpr (BLEND) {
                 // the alpha plane is never read from memory: 'Rate' is a constant, 'Gradient' the float32 ramp of
                 // homography.py:260-265 (linspace gives exact integers; float64 divide, * 0.5, stored as float32);
                 // texel (0,0) is the one bilinear() blanks (the ramp is 0 there anyway)
@@ -87,15 +86,16 @@ __global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
             }
         }
     }
-    if (!a.blend) {                  // paste, outside imgQ: truncated warp (transformImageH's astype(uint8)) or 0
+    uint32_t out = 0u;
+    if constexpr (!BLEND) {          // paste, outside imgQ: truncated warp (transformImageH's astype(uint8)) or 0
 #pragma unroll
-        for (int k = 0; k < 3; ++k) out[k] = (unsigned char)(int)t_rgb[k];
-        return;
+        for (int k = 0; k < 3; ++k) out |= (uint32_t)(unsigned char)(int)t_rgb[k] << (8 * k);
+        return out;
     }
     // float32 canvas: rgb = imgQ (or 0), alpha = alpha_q_in / alpha_q_out; blended inside the warped rectangle
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-        const float cq = in_q ? (float)q[k] : 0.f;
+        const float cq = (float)((q >> (8 * k)) & 0xffu);       // 0 outside imgQ
         float v = cq;
         if (in_t) {
             const double qa = (double)(in_q ? a.alpha_q_in : a.alpha_q_out);
@@ -103,7 +103,33 @@ __global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
             const double r = (qa / base) * (double)cq + (t_a / base) * t_rgb[k];
             v = (float)r;            // assignment into the float32 canvas
         }
-        out[k] = (unsigned char)(int)v;
+        out |= (uint32_t)(unsigned char)(int)v << (8 * k);
+    }
+    return out;
+}
+
+// 4 consecutive canvas pixels per lane: taps and imgQ pixels come in as dwords, the 12 output bytes leave in one store
+// (the texture-address path charges per lane and instruction, not per byte: 12 byte loads + 3 byte stores per pixel
+//  made the one-pixel-per-thread form of round 1 2.4x slower)
+constexpr int ST_PX = 4;
+template <bool BLEND>
+__global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
+    const int cx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * ST_PX;
+    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cx0 >= a.fw || cy >= a.fh) return;
+    const size_t t_bytes = (size_t)a.t_h * a.t_w * 3, q_bytes = (size_t)a.q_h * a.q_w * 3;
+    unsigned char* out = a.dst + ((size_t)cy * a.fw + cx0) * 3;
+    uint32_t px[ST_PX];
+#pragma unroll
+    for (int j = 0; j < ST_PX; ++j) px[j] = cx0 + j < a.fw ? stitch_pixel<BLEND>(a, cx0 + j, cy, t_bytes, q_bytes) : 0u;
+    if (cx0 + ST_PX <= a.fw) {
+        pk3 w;
+        w.a = px[0] | (px[1] << 24);
+        w.b = (px[1] >> 8) | (px[2] << 16);
+        w.c = (px[2] >> 16) | (px[3] << 8);
+        __builtin_memcpy(out, &w, 12);
+    } else {
+        for (int j = 0; cx0 + j < a.fw; ++j) { out[3 * j] = (unsigned char)px[j]; out[3 * j + 1] = (unsigned char)(px[j] >> 8); out[3 * j + 2] = (unsigned char)(px[j] >> 16); }
     }
 }
 
@@ -148,7 +174,8 @@ extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const 
     a.alpha_q_in = blend == 2 ? 1.0f                   // imgn[q-rect, 3] = 1                                 (homography.py:329)
                               : (float)(1 + 1e-10 - rate);   // imgn[q-rect, 3] = 1 + 1e-10 - blendrate       (float32 array)
     a.alpha_q_out = (float)1e-10;                      // imgn[:, :, 3] += 1e-10 on a float32 zero
-    const dim3 grid((canvas_w + 63) / 64, (canvas_h + 3) / 4), block(256);
-    hipLaunchKernelGGL(stitch_kernel, grid, block, 0, s, a);
+    const dim3 grid((canvas_w + 64 * ST_PX - 1) / (64 * ST_PX), (canvas_h + 3) / 4), block(256);
+    if (blend) hipLaunchKernelGGL(stitch_kernel<true>, grid, block, 0, s, a);
+    else hipLaunchKernelGGL(stitch_kernel<false>, grid, block, 0, s, a);
     return check_launch();
 }
