@@ -191,6 +191,52 @@ class GpuBackend:
             "sampling": "device Philox4x32-10, 4 distinct correspondences (non-parity mode)"}}
 
 
+def synthetic_correspondences(M, seed=42):
+    """SURVEY 8(d) scaling set: Hs-projected uniform points in [0, 4000)^2 + N(0, 1 px) noise + 40 % uniform outliers."""
+    rng = np.random.default_rng(seed)
+    Hs = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+    A = rng.uniform(0, 4000, (M, 2))
+    P = np.c_[A, np.ones(M)] @ Hs.T
+    B = P[:, :2] / P[:, 2:] + rng.normal(0, 1.0, (M, 2))
+    out = rng.random(M) < 0.4
+    B[out] = rng.uniform(0, 4000, (int(out.sum()), 2))
+    return A.astype(np.float32), B.astype(np.float32), rng
+
+
+def _scaling_set_leg(self, sync_all):
+    """K = 10 000 hypotheses on the synthetic sets of SURVEY 8(d): M = 1 024 and 16 384 correspondences (points streamed
+    per hypothesis instead of held in registers)."""
+    torch, k = self.torch, self.kernels
+    report = {}
+    K = 10000
+    for M in (1024, 16384):
+        A, B, rng = synthetic_correspondences(M)
+        pa, pb = torch.from_numpy(A).to(self.dev), torch.from_numpy(B).to(self.dev)
+        idx = torch.from_numpy(rng.integers(0, M, (K, 4)).astype(np.int32)).to(self.dev)
+        need = k.need_count(M, 70, 4)
+        ws = k.SearchWorkspace(K, M, self.dev, want_masks=False)
+
+        def step():
+            k.ransac_search(pa, pb, idx, 3.0, "fwd", need, ws)
+            return ws.best.cpu()
+
+        for _ in range(2):
+            step()
+        sync_all()
+        t0 = time.perf_counter()
+        R = 10
+        for _ in range(R):
+            best = step()
+        sync_all()
+        tr = time.perf_counter() - t0
+        winner, cnt, early = k.decode_best(best.numpy(), K)
+        report["M=%d K=%d" % (M, K)] = {"hyp_per_s": round(K * R / tr, 1), "us_per_run": round(tr / R * 1e6, 1),
+                                         "pair_evals_per_s": round(K * R * M / tr, 1), "winner": winner, "winner_count": cnt,
+                                         "inlier_fraction_planted": 0.6}
+    return {"scaling_set": report}
+
+
+GpuBackend.scaling_set_leg = _scaling_set_leg
 GpuBackend.other_kernels_leg = lambda self, w, h, nb: _other_kernels_leg(self, w, h, nb)
 GpuBackend.config4_leg = lambda self: _config4_leg(self)
 
@@ -410,6 +456,8 @@ def ransac_legs(backend, dist, world, rank, sync_all, max_over_ranks):
 
     if world == 1:
         report.update(backend.batched_search_leg(sync_all))
+        if hasattr(backend, "scaling_set_leg"):
+            report.update(backend.scaling_set_leg(sync_all))
     report["correspondences"] = 185
     report["includes"] = "K1 (also clears the keys) + K2 + argmax pass%s + 16-byte readback per run" % (" + all-reduce(max)" if world > 1 else "")
     return {"ransac": report}
