@@ -54,9 +54,12 @@ RWH_API const char* rwh_strerror(int code);
 /*
  * Lab / test hook, not part of the data path: pins a launch heuristic process-wide (value 0 = back to the library's
  * own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
- * hypotheses per wavefront of the scorer (1..64).  Results never depend on either (tests/test_gpu_parity.py).
+ * hypotheses per wavefront of the scorer (1..64); RWH_TUNE_SCORE_EXACT: 1 = the scorer skips its reciprocal-based
+ * filter and runs the two IEEE divisions for every pair (the filter only ever decides pairs that clear the threshold
+ * by a proven error band, so counts and masks are the same either way).  Results never depend on any of them
+ * (tests/test_gpu_parity.py).
  */
-enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1 };
+enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1, RWH_TUNE_SCORE_EXACT = 2 };
 RWH_API int rwh_lab_tune(int knob, int value);
 
 /*

@@ -227,6 +227,41 @@ __device__ __forceinline__ float proj_err(const float (&h)[9], float x, float y,
     return sqrtf(proj_sq(h, x, y, xp, yp));  // correctly rounded (__fsqrt_rn would lower to the approximate native sqrt)
 }
 
+// ---- K2's filter: decide most pairs without the two IEEE divisions ---------------------------------------------------
+// The reference's decision per pair is dist < th with dist computed in float32 through two correctly rounded divisions
+// (22 of the ~35 instructions of a pair).  proj_fast replaces them with q~ = a * rcp(den): the numerators and the
+// denominator are the SAME float32 values as in proj(); v_rcp_f32 is accurate to 1 ulp, so |q~ - q^| <= 2^-22 |q^|
+// against the correctly rounded quotient q^, as long as den is a normal number whose reciprocal is normal too
+// (`den_ok`; NaNs fail it).  A pair whose two answers could differ has q^ or q~ within th of the target, hence
+// |q| <= |target| + th, and its float32 distance moves by less than 2^-21 (|tx| + |ty| + 2 th) + 2^-21 th.  The band
+// below is four times that: a pair is decided here only when its approximate distance clears th by the band on either
+// side; everything else (and every NaN) makes the whole 64-pair word take the exact path.  Counts and masks therefore
+// stay bit-identical to the reference's, and on real data fewer than 1 % of the words take the exact path.
+struct Band { float lo, hi; };      // fwd / backward: limits on the SQUARED distance; reproj: on the sum of distances
+__device__ __forceinline__ float band_margin(float tx, float ty, float thf) {
+    return (fabsf(tx) + fabsf(ty) + 2.f * thf + 2.f) * 0x1p-19f;
+}
+__device__ __forceinline__ Band band_sq(float tx, float ty, float thf) {
+    const float mgn = band_margin(tx, ty, thf);
+    const float lo = fmaxf(thf - mgn, 0.f), hi = thf + mgn;
+    return Band{lo * lo * (1.f - 0x1p-20f), hi * hi * (1.f + 0x1p-20f)};
+}
+__device__ __forceinline__ float proj_sq_fast(const float (&h)[9], float x, float y, float xp, float yp, float& den) {
+    float a0 = h[0] * x; a0 = fmaf(h[1], y, a0); a0 = a0 + h[2];
+    float a1 = h[3] * x; a1 = fmaf(h[4], y, a1); a1 = a1 + h[5];
+    float a2 = h[6] * x; a2 = fmaf(h[7], y, a2); a2 = a2 + h[8];
+    den = a2 + 1e-10f;                                  // usable when 2^-100 < |den| < 2^100 (the caller tests it)
+    const float r = __builtin_amdgcn_rcpf(den);
+    const float dx = a0 * r - xp, dy = a1 * r - yp;
+    return dx * dx + dy * dy;
+}
+__device__ __forceinline__ float proj_sq_fast(const float (&h)[9], float x, float y, float xp, float yp, bool& den_ok) {
+    float den;
+    const float sq = proj_sq_fast(h, x, y, xp, yp, den);
+    den_ok = (int)(fabsf(den) > 0x1p-100f) & (int)(fabsf(den) < 0x1p100f);
+    return sq;
+}
+
 // float64 inverse of a float32 3x3 rounded back to float32 (numpy.linalg.inv on a float32 array,
 // ransac.py:74).  Plain LU with partial pivoting and reciprocal scaling; agrees with LAPACK's
 // result after the float32 rounding (checked on the golden hypotheses).
@@ -288,7 +323,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
                                                     float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
                                                     float* __restrict__ errs, const int32_t* __restrict__ offsets,
                                                     int k_per, int mask_stride, const int32_t* __restrict__ stop_needs,
-                                                    unsigned long long* stop_keys) {
+                                                    unsigned long long* stop_keys, float thf, int filter) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int h_begin, h_end;
@@ -316,15 +351,40 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
     unsigned long long* stop_word = stop_keys ? stop_keys + 2 * (size_t)stop_p + 1 : nullptr;
 
     float2 ra[WORDS > 0 ? WORDS : 1], rb[WORDS > 0 ? WORDS : 1];
+    Band band[WORDS > 0 ? WORDS : 1];
+    const bool fast = filter && !errs;                           // uniform; the loss values themselves need the exact path
+    auto make_band = [&](float2 a, float2 b) -> Band {
+        if constexpr (LOSS == RWH_LOSS_FWD) return band_sq(b.x, b.y, thf);
+        else if constexpr (LOSS == RWH_LOSS_BACKWARD) return band_sq(a.x, a.y, thf);
+        else {
+            const float mgn = band_margin(a.x, a.y, thf) + band_margin(b.x, b.y, thf);
+            return Band{thf - mgn, thf + mgn};
+        }
+    };
     if constexpr (WORDS > 0) {
 #pragma unroll
         for (int w = 0; w < WORDS; ++w) {
             const int j = w * 64 + lane;
             ra[w] = j < m ? reinterpret_cast<const float2*>(pa)[j] : float2{0.f, 0.f};
             rb[w] = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
+            band[w] = make_band(ra[w], rb[w]);
         }
     }
-    for (int hyp = h_begin; hyp < h_end; ++hyp) {
+    // The matrices of HB consecutive hypotheses are contiguous in `hs`: ONE coalesced vector load fetches them (lane l =
+    // float l of the block), the next block's load is in flight while this block is scored, and a hypothesis takes its
+    // nine floats with v_readlane (uniform lane index) -- straight into the aligned SGPR pairs the packed multiplies want.
+    constexpr int HB = 7;                                          // 63 floats per block
+    auto fetch = [&](int first) -> float {
+        const int n = 9 * min(HB, h_end - first);
+        return (first < h_end && lane < n) ? hs[9 * (size_t)first + lane] : 0.f;
+    };
+    float hv = fetch(h_begin);
+    for (int hyp0 = h_begin; hyp0 < h_end; hyp0 += HB) {
+    const float hv_next = fetch(hyp0 + HB);
+    const int nb = min(HB, h_end - hyp0);
+#pragma unroll 1
+    for (int q = 0; q < nb; ++q) {
+        const int hyp = hyp0 + q;
         if (stop_word) {
             const unsigned long long done = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             const int local = hyp - stop_p * k_per;
@@ -336,11 +396,34 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
         }
         float h[9], hi[9];
 #pragma unroll
-        for (int i = 0; i < 9; ++i) h[i] = hs[9 * (size_t)hyp + i];   // uniform address: scalar loads
+        for (int i = 0; i < 9; ++i) h[i] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hv), 9 * q + i));
         if constexpr (LOSS != RWH_LOSS_FWD) inverse3(h, hi);
         int count = 0;
-        auto score = [&](int w, float2 a, float2 b) {
+        auto score = [&](int w, float2 a, float2 b, const Band& bd) {
             const int j = w * 64 + lane;
+            if (fast) {
+                const int rem = m - w * 64;                                   // pairs in this word (uniform)
+                const unsigned long long valid = rem >= 64 ? ~0ull : ((1ull << rem) - 1ull);
+                bool in, sure;
+                if constexpr (LOSS == RWH_LOSS_REPROJ) {
+                    bool ok1, ok2;
+                    const float e = __builtin_amdgcn_sqrtf(proj_sq_fast(h, a.x, a.y, b.x, b.y, ok1)) +
+                                    __builtin_amdgcn_sqrtf(proj_sq_fast(hi, b.x, b.y, a.x, a.y, ok2));
+                    in = e < bd.lo;
+                    sure = (in | (e > bd.hi)) & ok1 & ok2;
+                } else {
+                    bool ok;
+                    const float sq = LOSS == RWH_LOSS_FWD ? proj_sq_fast(h, a.x, a.y, b.x, b.y, ok) : proj_sq_fast(hi, b.x, b.y, a.x, a.y, ok);
+                    in = sq < bd.lo;
+                    sure = (in | (sq > bd.hi)) & ok;
+                }
+                if ((~__ballot(sure) & valid) == 0ull) {                      // every pair of the word is decided
+                    const unsigned long long bal = __ballot(in) & valid;
+                    count += __popcll(bal);
+                    if (masks && lane == 0) masks[(size_t)hyp * mask_stride + w] = bal;
+                    return;
+                }
+            }
             bool inl = false;
             if (j < m) {
                 if constexpr (LOSS == RWH_LOSS_REPROJ) {
@@ -364,14 +447,14 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
         if constexpr (WORDS > 0) {
 #pragma unroll
             for (int w = 0; w < WORDS; ++w)
-                if (w < words) score(w, ra[w], rb[w]);
+                if (w < words) score(w, ra[w], rb[w], band[w]);
                 else if (masks && w < mask_stride && lane == 0) masks[(size_t)hyp * mask_stride + w] = 0;   // batched: shorter problem
         } else {
             for (int w = 0; w < words; ++w) {
                 const int j = w * 64 + lane;
                 const float2 a = j < m ? reinterpret_cast<const float2*>(pa)[j] : float2{0.f, 0.f};
                 const float2 b = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
-                score(w, a, b);
+                score(w, a, b, make_band(a, b));
             }
             if (masks && lane == 0)
                 for (int w = words; w < mask_stride; ++w) masks[(size_t)hyp * mask_stride + w] = 0;
@@ -380,6 +463,155 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
             counts[hyp] = count;
             if (stop_word && count >= stop_need) atomicMax(stop_word, 0xFFFFFFFFull - (unsigned long long)(hyp - stop_p * k_per));
         }
+    }
+    hv = hv_next;
+    }
+}
+
+// K2, filter form (counts + optional masks, M <= 256: the points and their bands stay in registers).  PMC on the
+// general kernel above (batched search, 640 000 hypotheses): VALU 89 % busy with the divisions, 59 % with the filter in
+// it -- and no faster, because its ~147 SALU instructions per hypothesis (mask bookkeeping and uniform branches per
+// 64-pair word) then fill the CU's one scalar issue slot per clock.  This kernel decides all words of a hypothesis with
+// straight-line code and branches ONCE, to the exact arithmetic, if any pair of the hypothesis is inside its band.
+template <int LOSS, int WORDS, bool MASKS>
+__global__ __launch_bounds__(256) void score_filter_kernel(const float* __restrict__ hs, const float* __restrict__ pa,
+                                                           const float* __restrict__ pb, int m, int k, int hpw, double th,
+                                                           float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
+                                                           const int32_t* __restrict__ offsets, int k_per, int mask_stride,
+                                                           const int32_t* __restrict__ stop_needs, unsigned long long* stop_keys,
+                                                           float thf) {
+    const int lane = threadIdx.x & 63;
+    const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    int h_begin, h_end;
+    if (offsets) {   // batched mode: a wave stays inside one problem
+        const int wpp = (k_per + hpw - 1) / hpw;
+        const int p = wid / wpp, chunk = wid - p * wpp;
+        if ((long long)p * k_per >= k) return;
+        const int base = offsets[p];
+        m = offsets[p + 1] - base;
+        pa += 2 * (size_t)base; pb += 2 * (size_t)base;
+        h_begin = p * k_per + chunk * hpw;
+        h_end = min((p + 1) * k_per, h_begin + hpw);
+    } else {
+        h_begin = wid * hpw;
+        if (h_begin >= k) return;
+        h_end = min(k, h_begin + hpw);
+    }
+    const int stop_p = stop_keys ? h_begin / k_per : 0;
+    const int stop_need = stop_keys ? stop_needs[stop_p] : 0;
+    unsigned long long* stop_word = stop_keys ? stop_keys + 2 * (size_t)stop_p + 1 : nullptr;
+
+    float2 ra[WORDS], rb[WORDS];
+    Band band[WORDS];
+    unsigned long long valid[WORDS];                              // the pairs that exist in each word (uniform)
+#pragma unroll
+    for (int w = 0; w < WORDS; ++w) {
+        const int j = w * 64 + lane;
+        ra[w] = j < m ? reinterpret_cast<const float2*>(pa)[j] : float2{0.f, 0.f};
+        rb[w] = j < m ? reinterpret_cast<const float2*>(pb)[j] : float2{0.f, 0.f};
+        if constexpr (LOSS == RWH_LOSS_FWD) band[w] = band_sq(rb[w].x, rb[w].y, thf);
+        else if constexpr (LOSS == RWH_LOSS_BACKWARD) band[w] = band_sq(ra[w].x, ra[w].y, thf);
+        else {
+            const float mgn = band_margin(ra[w].x, ra[w].y, thf) + band_margin(rb[w].x, rb[w].y, thf);
+            band[w] = Band{thf - mgn, thf + mgn};
+        }
+        const int rem = m - w * 64;
+        valid[w] = rem >= 64 ? ~0ull : rem <= 0 ? 0ull : ((1ull << rem) - 1ull);
+    }
+    constexpr int HB = 7;
+    auto fetch = [&](int first) -> float {
+        const int n = 9 * min(HB, h_end - first);
+        return (first < h_end && lane < n) ? hs[9 * (size_t)first + lane] : 0.f;
+    };
+    float hv = fetch(h_begin);
+    int32_t* cnt_out = counts + h_begin;                          // running output positions: no 64-bit multiplies in the loop
+    uint64_t* mask_out = MASKS ? masks + (size_t)h_begin * mask_stride : nullptr;
+    for (int hyp0 = h_begin; hyp0 < h_end; hyp0 += HB) {
+        const float hv_next = fetch(hyp0 + HB);
+        const int nb = min(HB, h_end - hyp0);
+        // 'backward' / 'reproj' need inv(H) (ransac.py:74): lane q inverts hypothesis q of the block -- once per block
+        // instead of once per hypothesis in every lane
+        float hiv[9];
+        if constexpr (LOSS != RWH_LOSS_FWD) {
+            float mine[9];
+            const int src = 9 * min(lane, HB - 1);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) mine[i] = __shfl(hv, src + i);
+            inverse3(mine, hiv);
+        }
+#pragma unroll 1
+        for (int q = 0; q < nb; ++q, ++cnt_out, mask_out += (MASKS ? mask_stride : 0)) {
+            const int hyp = hyp0 + q;
+            if (stop_word) {
+                const unsigned long long done = __hip_atomic_load(stop_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int local = hyp - stop_p * k_per;
+                if (done != 0ull && (long long)(0xFFFFFFFFull - done) < (long long)local) {      // an earlier hypothesis already exits
+                    if (lane == 0) *cnt_out = -1;
+                    if (MASKS && lane < mask_stride) mask_out[lane] = 0;
+                    continue;
+                }
+            }
+            float h[9], hi[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) h[i] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hv), 9 * q + i));
+            if constexpr (LOSS != RWH_LOSS_FWD) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) hi[i] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hiv[i]), q));
+            }
+            unsigned long long inb[WORDS], undecided = 0ull;
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) {
+                // one ballot per comparison (each is the comparison's own SGPR mask), combined on the scalar unit: a ballot
+                // of a combined predicate costs two more VALU instructions, and VALU is what bounds this kernel
+                unsigned long long b_in, b_sure;
+                if constexpr (LOSS == RWH_LOSS_REPROJ) {
+                    float d1, d2;
+                    const float e = __builtin_amdgcn_sqrtf(proj_sq_fast(h, ra[w].x, ra[w].y, rb[w].x, rb[w].y, d1)) +
+                                    __builtin_amdgcn_sqrtf(proj_sq_fast(hi, rb[w].x, rb[w].y, ra[w].x, ra[w].y, d2));
+                    b_in = __ballot(e < band[w].lo);
+                    b_sure = (b_in | __ballot(e > band[w].hi)) & __ballot(fabsf(d1) > 0x1p-100f) & __ballot(fabsf(d1) < 0x1p100f) &
+                             __ballot(fabsf(d2) > 0x1p-100f) & __ballot(fabsf(d2) < 0x1p100f);
+                } else {
+                    float d;
+                    const float sq = LOSS == RWH_LOSS_FWD ? proj_sq_fast(h, ra[w].x, ra[w].y, rb[w].x, rb[w].y, d)
+                                                          : proj_sq_fast(hi, rb[w].x, rb[w].y, ra[w].x, ra[w].y, d);
+                    b_in = __ballot(sq < band[w].lo);
+                    b_sure = (b_in | __ballot(sq > band[w].hi)) & __ballot(fabsf(d) > 0x1p-100f) & __ballot(fabsf(d) < 0x1p100f);
+                }
+                inb[w] = b_in & valid[w];
+                undecided |= ~b_sure & valid[w];
+            }
+            if (undecided != 0ull) {                              // rare: some pair is inside its band (or not a number)
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) {
+                    bool inl;
+                    if constexpr (LOSS == RWH_LOSS_REPROJ) {
+                        float e = proj_err(h, ra[w].x, ra[w].y, rb[w].x, rb[w].y);
+                        e = e + proj_err(hi, rb[w].x, rb[w].y, ra[w].x, ra[w].y);
+                        inl = (double)e < th;
+                    } else {
+                        const float sq = LOSS == RWH_LOSS_FWD ? proj_sq(h, ra[w].x, ra[w].y, rb[w].x, rb[w].y)
+                                                              : proj_sq(hi, rb[w].x, rb[w].y, ra[w].x, ra[w].y);
+                        inl = sq < sq_limit;
+                    }
+                    inb[w] = __ballot(inl) & valid[w];
+                }
+            }
+            int count = 0;
+#pragma unroll
+            for (int w = 0; w < WORDS; ++w) count += __popcll(inb[w]);
+            if constexpr (MASKS) {
+                unsigned long long mine = 0ull;                   // lane w stores word w: one store instruction per hypothesis
+#pragma unroll
+                for (int w = 0; w < WORDS; ++w) mine = lane == w ? inb[w] : mine;
+                if (lane < mask_stride) mask_out[lane] = mine;
+            }
+            if (lane == 0) {
+                *cnt_out = count;
+                if (stop_word && count >= stop_need) atomicMax(stop_word, 0xFFFFFFFFull - (unsigned long long)(hyp - stop_p * k_per));
+            }
+        }
+        hv = hv_next;
     }
 }
 
@@ -539,8 +771,25 @@ void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const f
     const dim3 block(256);
     if (mask_stride < 0) mask_stride = words;
     const float sq_limit = score_sq_limit(th);
+    // the filter's band arithmetic wants a positive threshold of ordinary size; anything else: exact path only
+    const int filter = (th > 1e-6 && th < 1e6 && !g_score_exact_only) ? 1 : 0;
+    const float thf = (float)th;
+    if (filter && !d_err && words <= 4) {      // the common case: counts (+ masks) of M <= 256 correspondences
+#define RWH_FILTER(W) do { if (d_masks) hipLaunchKernelGGL((score_filter_kernel<LOSS, W, true>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, \
+                                                          hpw, th, sq_limit, d_counts, d_masks, offsets, k_per, mask_stride, stop_needs, stop_keys, thf); \
+                           else hipLaunchKernelGGL((score_filter_kernel<LOSS, W, false>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, \
+                                                   hpw, th, sq_limit, d_counts, d_masks, offsets, k_per, mask_stride, stop_needs, stop_keys, thf); } while (0)
+        switch (words) {
+            case 1: RWH_FILTER(1); break;
+            case 2: RWH_FILTER(2); break;
+            case 3: RWH_FILTER(3); break;
+            default: RWH_FILTER(4); break;
+        }
+#undef RWH_FILTER
+        return;
+    }
 #define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, \
-                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride, stop_needs, stop_keys)
+                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride, stop_needs, stop_keys, thf, filter)
     switch (words <= 4 ? words : 0) {
         case 1: RWH_SCORE(1); break;
         case 2: RWH_SCORE(2); break;
@@ -562,8 +811,8 @@ extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const flo
     if (k == 0) return RWH_OK;
     hipStream_t s = static_cast<hipStream_t>(stream);
     // hypotheses per wave: enough waves to fill the chip (>= ~8 per SIMD) before a wave gets more than one
-    int hpw = k / (256 * 4 * 32);   // measured: 1 up to ~30 k hypotheses, 2-4 at 100 k (tools/k2time.py)
-    hpw = hpw < 1 ? 1 : (hpw > 8 ? 8 : hpw);
+    int hpw = k / 14000;            // measured (tools/k2_hpw_sweep.py): 1 up to ~20 k hypotheses, 7 at 100 k
+    hpw = hpw < 1 ? 1 : (hpw > 14 ? 14 : hpw);   // (the kernel fetches H in blocks of 7 hypotheses)
     if (g_force_score_hpw) hpw = g_force_score_hpw;   // lab override (rwh_lab_tune)
     const int waves = (k + hpw - 1) / hpw;
     const dim3 grid((waves + 3) / 4);
@@ -610,8 +859,9 @@ extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, co
                            (unsigned long long)seed, (unsigned)problem_base, d_idx);
     launch_dlt4(s, d_pts_a, d_pts_b, m_max, d_idx, (int)total, d_h, d_flags, d_offsets, k,
                 reinterpret_cast<unsigned long long*>(d_best), 2 * n_problems);   // also clears the P x 2 keys
-    int hpw = (int)(total / (256 * 4 * 32));
-    hpw = hpw < 1 ? 1 : (hpw > 8 ? 8 : hpw);
+    int hpw = (int)(total / 14000);
+    hpw = hpw < 1 ? 1 : (hpw > 14 ? 14 : hpw);
+    if (g_force_score_hpw) hpw = g_force_score_hpw;   // lab override (rwh_lab_tune)
     if (hpw > k) hpw = k;
     const long long waves = (long long)n_problems * ((k + hpw - 1) / hpw);
     const dim3 grid((unsigned)((waves + 3) / 4));

@@ -650,6 +650,73 @@ def test_scorer_threshold_edges(gpu):
                 assert np.array_equal(bits, want) and int(counts[i]) == int(want.sum()), (method, th, i)
 
 
+def test_scorer_filter_never_changes_a_decision(gpu):
+    """K2 decides most pairs from a * rcp(den) and a proven error band, and re-does a hypothesis with the two IEEE
+    divisions when any pair is inside the band (score_filter_kernel).  Counts and masks must equal the all-exact
+    kernel's (rwh_lab_tune RWH_TUNE_SCORE_EXACT) and the oracle's on inputs built to stress the band: pairs exactly on,
+    and one ulp around, the threshold; coordinates up to 1e5; hypotheses with a horizon crossing the points (den ~ 0),
+    huge, tiny, infinite and NaN entries; thresholds from 1e-3 to 1e4."""
+    from oracle import rwh_oracle as orc
+    from ransac_with_homography_amd import kernels, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(77)
+    for M, scale in ((185, 1200.0), (256, 1e5), (70, 30.0)):
+        X = rng.uniform(0, scale, (2, M)).astype(np.float32)
+        base = np.array([[1.01, 0.02, 3.0], [-0.015, 0.99, -2.0], [1e-6, -2e-6, 1.0]])
+        P = base @ np.vstack([X.astype(np.float64), np.ones(M)])
+        Y = (P[:2] / P[2]).astype(np.float32)
+        kind = rng.integers(0, 4, M)
+        Y[:, kind == 1] += rng.normal(0, 3.0, (2, int((kind == 1).sum()))).astype(np.float32)        # around a 5 px threshold
+        Y[:, kind == 2] = rng.uniform(0, scale, (2, int((kind == 2).sum()))).astype(np.float32)      # outliers
+        Y[0, kind == 3] += np.float32(5.0)                                                           # (nearly) on the threshold
+        hs = [base.astype(np.float32).reshape(9)]
+        for _ in range(120):
+            hs.append((base + rng.normal(0, 1, (3, 3)) * np.array([[1e-3, 1e-3, 1.0], [1e-3, 1e-3, 1.0], [1e-7, 1e-7, 1e-3]])).astype(np.float32).reshape(9))
+        for sc in (1e-30, 1e-20, 1e20, 1e30):                                                        # H is homogeneous: same answers, other magnitudes
+            hs.append((base * sc).astype(np.float32).reshape(9))
+        for j in range(12):                                                                          # the horizon through point j: den ~ 0 there
+            h = base.copy(); h[2] = [1.0 / max(X[0, j], 1.0), 0.0, -1.0 if X[0, j] >= 1.0 else -X[0, j]]
+            hs.append(h.astype(np.float32).reshape(9))
+        for bad in (np.nan, np.inf, -np.inf, 0.0):
+            for pos in (0, 4, 8):
+                h = base.astype(np.float32).reshape(9).copy(); h[pos] = bad
+                hs.append(h)
+        hs.append(np.zeros(9, np.float32))
+        Hs = np.stack(hs)
+        pa = torch.from_numpy(np.ascontiguousarray(X.T)).to(gpu)
+        pb = torch.from_numpy(np.ascontiguousarray(Y.T)).to(gpu)
+        Hd = torch.from_numpy(Hs).to(gpu)
+        for method in ("fwd", "backward", "reproj"):
+            with np.errstate(all="ignore"):
+                errs = []
+                for h in Hs:
+                    try:
+                        errs.append(orc.compute_loss(h.reshape(3, 3), X, Y, method))
+                    except np.linalg.LinAlgError:                    # singular H in 'backward' / 'reproj': the reference raises
+                        errs.append(None)
+            fin = np.concatenate([e[np.isfinite(e)] for e in errs if e is not None])
+            ths = [1e-3, 0.5, 5.0, 40.0, 1e4] + [float(v) for v in np.sort(fin[(fin > 1e-2) & (fin < 1e3)])[::97][:6]]
+            for th in ths:
+                got = {}
+                for exact in (1, 0):
+                    assert lib.rwh_lab_tune(_lib.RWH_TUNE_SCORE_EXACT, exact) == 0
+                    try:
+                        counts, masks, _ = kernels.score_count(Hd, pa, pb, th, method, 1 << 30, kernels.new_best(gpu))
+                    finally:
+                        lib.rwh_lab_tune(_lib.RWH_TUNE_SCORE_EXACT, 0)
+                    got[exact] = (counts.cpu().numpy(), masks.cpu().numpy())
+                assert np.array_equal(got[0][0], got[1][0]) and np.array_equal(got[0][1], got[1][1]), (M, method, th)
+                # against the oracle: every hypothesis for 'fwd'; the well-conditioned ones for the losses that invert H
+                # (the device inverts with its own float64 LU: equal to LAPACK's after the float32 rounding on ordinary
+                # matrices, not promised on singular / overflowing ones, where the reference raises or returns inf)
+                for i, e in enumerate(errs[:len(errs) if method == "fwd" else 121]):
+                    if e is None:
+                        continue
+                    want = e.astype(np.float64) < th
+                    bits = np.unpackbits(got[0][1][i].view(np.uint8), bitorder="little")[:M].astype(bool)
+                    assert np.array_equal(bits, want), (M, method, th, i)
+
+
 @pytest.mark.parametrize("M", [64, 65, 256, 257, 1000, 1024, 16384])
 def test_scorer_any_number_of_correspondences(gpu, M):
     """SURVEY 8d scaling set: synthetic correspondences (Hs-projected uniform points + 1 px noise + 40 % outliers).
