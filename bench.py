@@ -17,6 +17,7 @@ Workload (BASELINE.json configs[1], the configuration the metric is quoted on):
 Extra keys of the same JSON line:
   warp_8k       the north_star's 8K warp: 8 distinct 7680x4320 frames per launch, same kernel, with its own kernel
                 time / achieved GB/s / fraction of the HBM roofline (N = 1);
+  config5_batch_1080p  BASELINE config 5's warp: 512 distinct 1080p frames sharded by image, one launch per rank.
   strong_8k     the same 8 frames with the OUTPUT ROWS sharded over the ranks (sharded.warp_row_shard's row tiles, no
                 collective): fixed total work = the strong-scaling leg;
   ransac        hypotheses/s on matchespoints (10 000 and 100 000 hypotheses at N = 1; 100 000 sharded over the ranks with
@@ -320,6 +321,17 @@ def run_rank(args, backend, dist=None):
                                "mpix_per_s": round(F8 * oh8 * ow8 / 1e6 * 10 / el8, 1), "ms_per_step": round(el8 / 10 * 1e3, 4),
                                "kernel": plan8}
         del keep8, steps8
+        # ---- BASELINE config 5's warp: 512 distinct 1080p frames, sharded by image over the ranks, one launch each ------
+        F5 = 512 // world
+        step5, oh5, ow5, _, plan5, keep5 = backend.make_warp(F5, 1920, 1080, 5000 + rank)
+        el5, ms5 = timed(backend, step5, 5, 2, sync_all)
+        el5 = max_over_ranks(el5)
+        by5 = F5 * 3 * (1080 * 1920 + oh5 * ow5)
+        extras["config5_batch_1080p"] = {"workload": "512 frames 1920x1080 RGB u8 -> %dx%d u8, %d per rank in ONE launch (sharded by image, no collective)"
+                                                     % (oh5, ow5, F5), "scaling": "strong", "kernel": plan5, "kernel_ms_rank0": round(ms5, 4),
+                                         "mpix_per_s": round(world * F5 * oh5 * ow5 / 1e6 * 5 / el5, 1),
+                                         "frac_rank0": round(by5 / ms5 / 1e6 / HBM_PEAK_GBS, 4)}
+        del keep5, step5
         # ---- RANSAC ---------------------------------------------------------------------------------------------
         extras.update(ransac_legs(backend, dist, world, rank, sync_all, max_over_ranks))
         if world == 1:

@@ -561,9 +561,16 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
     const unsigned b = blockIdx.x;
     const unsigned logical = (b & 7u) * a.cpx + (b >> 3);   // XCD k walks logical blocks [k*cpx, (k+1)*cpx)
-    if (logical >= a.nblocks) return;
     const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;   // magic 0 <=> divisor 1
     const unsigned tx = logical - t * a.tiles_x;
+    {   // a patch that owns nothing does nothing: a block past the grid, or a patch of the moved last tile of a ragged row
+        // whose columns all belong to the tile on its left (out_w = 1921 leaves that tile ONE column).  (Folded into the one
+        // early return on purpose: a second `return` further down -- e.g. for patches below the last row -- costs the
+        // 64-VGPR uint8 kernel three spilled registers.)
+        const int w0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int own_from = (int)tx * 128 - min((int)tx * 128, a.out_w - 128);
+        if ((logical >= a.nblocks) | ((w0 % (128 / (1 << LOG_PW)) + 1) * (1 << LOG_PW) <= own_from)) return;
+    }
     const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
     const unsigned ty = t - img * a.tiles_y;
     const Coef& co = tab ? tab[img] : a.c;                  // uniform: scalar loads either way
@@ -928,6 +935,7 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const int rr_raw = (int)ty * 16 + wave_y + prow;
     const int rr = min(rr_raw, a.rows - 1);
     const int tcol0 = (int)tx * 128, tcol = min(tcol0, a.out_w - 128), tshift = tcol0 - tcol;
+    if ((wave_x + PW <= tshift) | ((int)ty * 16 + wave_y >= a.rows)) return;    // the patch owns no pixel (see fast8_body)
     const int lcol = wave_x + pq * 4, c0p = tcol + lcol;
     const bool store_any = rr_raw < a.rows;
     const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;

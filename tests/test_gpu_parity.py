@@ -994,6 +994,29 @@ def test_config5_batch_1080p(gpu):
             assert torch.equal(per[i], kernels.warp_backward(src[i].contiguous(), invs[i], grid, (1080, 1920), interp, dt)), (interp, i)
 
 
+def test_config5_whole_batch_512_frames(gpu):
+    """BASELINE config 5 at its full size on ONE GPU: 512 distinct 1080p frames (3.19 GB) in one launch -- every sampled
+    frame equals its own single-frame launch (bilinear uint8 / float32 and nearest), also with one homography per frame."""
+    from ransac_with_homography_amd import kernels
+    g = torch.Generator(device=gpu).manual_seed(1234)
+    src = torch.randint(0, 256, (512, 1080, 1920, 3), dtype=torch.uint8, generator=g, device=gpu)
+    inv = np.linalg.inv(H_BENCH)
+    grid = kernels.Grid(0, 1919, 1920, 0, 1079, 1080)
+    picks = (0, 1, 255, 256, 511)
+    for interp, dt in (("bilinear", torch.uint8), ("nn", torch.uint8), ("bilinear", torch.float32)):
+        full = kernels.warp_backward(src, inv, grid, (1080, 1920), interp, dt)
+        assert full.shape == (512, 1080, 1920, 3)
+        for b in picks:
+            assert torch.equal(kernels.warp_backward(src[b].contiguous(), inv, grid, (1080, 1920), interp, dt), full[b]), (interp, b)
+        del full
+    rng = np.random.default_rng(5)
+    invs = np.stack([np.linalg.inv(np.array([[np.cos(t), -np.sin(t), 30 * t], [np.sin(t), np.cos(t), 5.0], [0, 0, 1.0]]))
+                     for t in rng.uniform(-0.2, 0.2, 512)])
+    per = kernels.warp_backward(src, invs, grid, (1080, 1920), "bilinear", torch.uint8)
+    for b in picks:
+        assert torch.equal(kernels.warp_backward(src[b].contiguous(), invs[b], grid, (1080, 1920), "bilinear", torch.uint8), per[b]), b
+
+
 def _oracle_warp_on_grid(img, inv_h, xs, ys, bound_hw, snap=0.0):
     """numpy float64 restatement of homography.py:166-179 for an arbitrary output grid (the oracle's own
     interpolator on coordinates computed exactly like the reference computes them).  snap > 0: coordinates within `snap` of a
