@@ -699,6 +699,20 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
                         (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
 
+    // Border patches (4.8 % of a 4K frame's patches, 10.5 % of a 1080p frame's: some pixels map outside the source): the
+    // window is the corners' box clamped into the image -- by convexity it still holds every VALID pixel's taps -- and is
+    // staged like any other; the pixels then take their taps from the slab under their validity mask (below).  Not for
+    // windows that reach the last two source rows (a staging chunk may read 9 bytes past its last texel).
+    int wxmn = xmn, wymn = ymn, wnrows = nrows, wC = C;
+    bool border = false;
+    if (!staged & wpos) {
+        const int cx0 = smin(smax(xmn, 0), a.bound_w - 1), cx1 = smin(smax(xmx, 0), a.bound_w - 1);
+        const int cy0 = smin(smax(ymn, 0), a.bound_h - 1), cy1 = smin(smax(ymx, 0), a.bound_h - 1);
+        const int nr = smax(cy1 - cy0 + 2, Win::RPP), nc = (cx1 - cx0 + 5) >> 2;
+        border = (nr <= Win::ROWS) & (nc <= Win::LPRW) & (cy0 + nr - 1 <= a.src_h - 2);
+        if (border) { wxmn = cx0; wymn = cy0; wnrows = nr; wC = nc; }
+    }
+
     // ---- staging loads go out now: lane -> (row srow of the pass, chunk scol), fixed for the kernel ---------------------
     unsigned char* my = slab[wave];
     pk3 v[Win::PASSES];
@@ -707,9 +721,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const int srow = lane / Win::LPRW, scol = lane - srow * Win::LPRW;
     const bool sactive = (srow < Win::RPP) & (scol < C);
     const uint32_t wl = (uint32_t)(srow * Win::LPITCH + scol * 16);               // the lane's slab byte inside a pass
+    const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)scol));
     if (staged) {
         const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
-        const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)scol));
 #pragma unroll
         for (int p = 0; p < Win::PASSES; ++p) {
             if (p * Win::RPP < nrows && sactive) {                      // first half uniform: unused passes cost nothing
@@ -795,7 +809,89 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         return;
     }
 
-    // ---- border / oversize waves: masked gathers from global memory -----------------------------------
+    // ---- masked runs (border / oversize waves): validity per pixel, zero weights for the pixels outside the source ------
+    auto finish_masked_run = [&](const int h, const unsigned vbits) __attribute__((always_inline)) {
+        const int first = tshift - (lcol + (PW / 2) * h);
+        if constexpr (COMP) {
+            float o[FP_PX][3];
+            blend4<true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
+            uint32_t q[FP_PX];
+            const int cx = c0p + (PW / 2) * h;
+            const unsigned qin = comp_load_q(*cp, cy, cx, q);
+            unsigned tin = 0u;
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j)
+                tin |= (unsigned)((cy >= cp->tsy) & (cy < cp->tsy + cp->ht) & (cx + j >= cp->tsx) & (cx + j < cp->tsx + cp->wt)) << j;
+            // a pixel outside T never shows the warp, whatever its coordinate maps to (T is the reference's int()-truncated bbox)
+            float oz[FP_PX][3];
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j)
+#pragma unroll
+                for (int c = 0; c < 3; ++c) oz[j][c] = (tin & (1u << j)) ? o[j][c] : U8_BIAS;
+            comp_store(*cp, oz, tin & vbits, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
+        } else {
+            blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                                    store_any & (first <= 3 * PSTR), max(first, 0));
+        }
+    };
+    // 0 <= s <= bound-1 on the bit patterns: positive doubles order like unsigned integers; negative values and NaNs have
+    // patterns outside [MAGIC_BITS, xmax_bits]
+    auto pixel_valid = [&](int j) __attribute__((always_inline)) -> bool {
+        const unsigned long long ubx = ((unsigned long long)hx[j] << 32) | lx[j], uby = ((unsigned long long)hy[j] << 32) | ly[j];
+        return (ubx >= MAGIC_BITS) & (ubx <= a.xmax_bits) & (uby >= MAGIC_BITS) & (uby <= a.ymax_bits);
+    };
+
+    // ---- border waves: taps from the clamped window's slab -----------------------------------------------------------
+    if (border) {
+        {   // stage the clamped window with registers of its own (sharing the main path's `v` stretched its live range over
+            // both paths and made the compiler spill the staging loads)
+            const unsigned char* gbase = simg + (size_t)((uint32_t)wymn * pitch + (uint32_t)wxmn * 3u);   // uniform
+            const bool bactive = (srow < Win::RPP) & (scol < wC);
+            pk3 vb[Win::PASSES];
+#pragma unroll
+            for (int p = 0; p < Win::PASSES; ++p)
+                if (p * Win::RPP < wnrows && bactive)
+                    __builtin_memcpy(&vb[p], gbase + (size_t)((uint32_t)min(p * Win::RPP, wnrows - Win::RPP) * pitch) + goff, 12);
+#pragma unroll
+            for (int p = 0; p < Win::PASSES; ++p)
+                if (p * Win::RPP < wnrows && bactive) {
+                    uint4 t4;
+                    t4.x = vb[p].a;
+                    t4.y = __builtin_amdgcn_alignbyte(vb[p].b, vb[p].a, 3);
+                    t4.z = __builtin_amdgcn_alignbyte(vb[p].c, vb[p].b, 2);
+                    t4.w = vb[p].c >> 8;
+                    *reinterpret_cast<uint4*>(my + (uint32_t)min(p * Win::RPP, wnrows - Win::RPP) * (uint32_t)Win::LPITCH + wl) = t4;
+                }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+        const uint32_t bx = MAGIC_HI + (uint32_t)wxmn, by = MAGIC_HI + (uint32_t)wymn;          // uniform
+        const uint32_t rx_max = (uint32_t)(4 * wC - 2), ry_max = (uint32_t)(wnrows - 2);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            unsigned vbits = 0u;
+            run_coords(h);
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const bool valid = pixel_valid(j);
+                weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
+                vbits |= (unsigned)valid << j;
+                // window-relative texel, kept inside the window whatever the coordinate is: a pixel outside the source has
+                // zero weights, and a valid one lies in the window by convexity (up to a floor() that rounding moved across
+                // an integer, where the tap that could fall outside has a weight < 2^-32)
+                const uint32_t rx = min(hx[j] - bx, rx_max), ry = min(hy[j] - by, ry_max);
+                const uint32_t lo = mad24_s(ry, (uint32_t)Win::LPITCH, rx << 2);
+                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(my + lo);
+                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(my + lo + Win::LPITCH);
+                a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
+            }
+            finish_masked_run(h, vbits);
+        }
+        return;
+    }
+
+    // ---- everything else (windows that do not fit, the last two source rows, W <= 0): masked gathers from global memory --
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         uint32_t off[FP_PX];
@@ -804,17 +900,17 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         run_coords(h);
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j) {
-            // 0 <= s <= bound-1 on the bit patterns: positive doubles order like unsigned integers; negative
-            // values and NaNs have patterns outside [MAGIC_BITS, xmax_bits]
-            const unsigned long long ubx = ((unsigned long long)hx[j] << 32) | lx[j], uby = ((unsigned long long)hy[j] << 32) | ly[j];
-            const bool valid = (ubx >= MAGIC_BITS) & (ubx <= a.xmax_bits) & (uby >= MAGIC_BITS) & (uby <= a.ymax_bits);
+            const bool valid = pixel_valid(j);
             const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
             weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
             off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
             near_end |= valid & (iy > a.src_h - 3);
             vbits |= (unsigned)valid << j;
         }
-        if (!__any(near_end)) {
+        if (!__any(vbits != 0u)) {           // the whole run maps outside the source (the corners of a warped quad's bounding
+#pragma unroll                           // box): every weight is 0 already, nothing to load
+            for (int j = 0; j < FP_PX; ++j) { a0[j] = 0u; b0[j] = 0u; a1[j] = 0u; b1[j] = 0u; }
+        } else if (!__any(near_end)) {
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 const pk2 r0 = ld8(simg + off[j]);
@@ -834,39 +930,18 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 b1[j] = simg[o11] | (simg[o11 + 1] << 8) | (simg[o11 + 2] << 16);
             }
         }
-        const int first = tshift - (lcol + (PW / 2) * h);
-        if constexpr (COMP) {
-            float o[FP_PX][3];
-            blend4<true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
-            uint32_t q[FP_PX];
-            const int cx = c0p + (PW / 2) * h;
-            const unsigned qin = comp_load_q(*cp, cy, cx, q);
-            unsigned tin = 0u;
-#pragma unroll
-            for (int j = 0; j < FP_PX; ++j)
-                tin |= (unsigned)((cy >= cp->tsy) & (cy < cp->tsy + cp->ht) & (cx + j >= cp->tsx) & (cx + j < cp->tsx + cp->wt)) << j;
-            // a pixel outside T never shows the warp, whatever its coordinate maps to (T is the reference's int()-truncated bbox)
-            float oz[FP_PX][3];
-#pragma unroll
-            for (int j = 0; j < FP_PX; ++j)
-#pragma unroll
-                for (int k = 0; k < 3; ++k) oz[j][k] = (tin & (1u << j)) ? o[j][k] : U8_BIAS;
-            comp_store(*cp, oz, tin & vbits, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
-        } else {
-            blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
-                                    store_any & (first <= 3 * PSTR), max(first, 0));
-        }
+        finish_masked_run(h, vbits);
     }
 }
 
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : 5)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
 // canvas compositor form (uint8): the output grid is the canvas, imgQ is composited in the epilogue (CompArgs)
 template <int LOG_PW>
-__global__ __launch_bounds__(256, RWH_F8_WAVES) void warp_rgb8_comp(const FastArgs a, const CompArgs c) { fast8_body<unsigned char, LOG_PW, true>(a, nullptr, &c); }
+__global__ __launch_bounds__(256, 6) void warp_rgb8_comp(const FastArgs a, const CompArgs c) { fast8_body<unsigned char, LOG_PW, true>(a, nullptr, &c); }
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : RWH_F8_WAVES)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : 5)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
