@@ -536,12 +536,12 @@ inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // h
     return nrows >= 64 / lprw && nrows <= rows && ((ntex + 3) >> 2) <= lprw;
 }
 
-#ifndef RWH_F8_WAVES
-#define RWH_F8_WAVES 1
-#endif
-#ifndef RWH_F8_WAVES_U8
-#define RWH_F8_WAVES_U8 8   // uint8 output: 64 VGPRs (no spills) and 20 160 B of LDS per block -> 8 waves per SIMD (+2.4 % over 6)
-#endif
+// Waves per SIMD the register allocator must leave room for.  uint8 output: 64 VGPRs (no spills) and 20 160 B of LDS per
+// block -> 8 waves (+2.4 % over 6); 128 x 4 patches 7, 32 x 16 patches 6 (their windows need the LDS).  float32 output (3 KB
+// more LDS per wave for the re-deal) and the compositor: LDS allows 5 (4 for 32 x 16 patches) and 6.
+template <typename DstT, int LOG_PW> constexpr int f8_waves() {
+    return sizeof(DstT) == 1 ? (LOG_PW == 7 ? 7 : LOG_PW == 5 ? 6 : 8) : (LOG_PW == 5 ? 4 : 5);
+}
 // Order of work inside a wave: the two END pixels of every lane (own reciprocals) give the footprint and the staging
 // loads go out at once; the other six pixels are computed run by run (3 + 3, one batch inversion each) right before
 // their taps are read, so that only 4 pixels' coordinates, weights and taps are live at a time -- the kernel is
@@ -935,13 +935,13 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 }
 
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : 5)) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+__global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
 // canvas compositor form (uint8): the output grid is the canvas, imgQ is composited in the epilogue (CompArgs)
 template <int LOG_PW>
 __global__ __launch_bounds__(256, 6) void warp_rgb8_comp(const FastArgs a, const CompArgs c) { fast8_body<unsigned char, LOG_PW, true>(a, nullptr, &c); }
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
-__global__ __launch_bounds__(256, (sizeof(DstT) == 1 ? (LOG_PW == 7 ? RWH_F8_WAVES_U8 - 1 : LOG_PW == 5 ? RWH_F8_WAVES_U8 - 2 : RWH_F8_WAVES_U8) : 5)) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+__global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
