@@ -305,7 +305,7 @@ def run_rank(args, backend, dist=None):
         F8 = 8
         if world == 1:
             step8, oh8, ow8, _, plan8, keep8 = backend.make_warp(F8, 7680, 4320, 4321)
-            _, ms8 = timed(backend, step8, 20, 5, sync_all)
+            _, ms8 = timed(backend, step8, 20, 5, sync_all, PREWARM_MS)
             by8 = F8 * 3 * (4320 * 7680 + oh8 * ow8)
             extras["warp_8k"] = {"workload": "%d frames 7680x4320 RGB u8 -> %dx%d u8 per launch" % (F8, oh8, ow8), "kernel": plan8,
                                  "kernel_ms": round(ms8, 4), "mpix_per_s": round(F8 * oh8 * ow8 / ms8 / 1e3, 1),
@@ -314,7 +314,7 @@ def run_rank(args, backend, dist=None):
                                  "read_only_frac": round(F8 * 3 * 4320 * 7680 / ms8 / 1e6 / HBM_PEAK_GBS, 4)}
             del keep8, step8
         steps8, oh8, ow8, rows8, plan8, keep8 = backend.make_warp(F8, 7680, 4320, 4321, rows_of=(rank, world))
-        el8, ms8 = timed(backend, steps8, 10, 3, sync_all)
+        el8, ms8 = timed(backend, steps8, 10, 3, sync_all, PREWARM_MS)
         el8 = max_over_ranks(el8)
         extras["strong_8k"] = {"workload": "%d frames 7680x4320 -> %dx%d, output rows sharded over %d rank(s) (row tiles, no collective)"
                                            % (F8, oh8, ow8, world), "scaling": "strong", "rows_of_rank0": list(rows8),
@@ -324,7 +324,7 @@ def run_rank(args, backend, dist=None):
         # ---- BASELINE config 5's warp: 512 distinct 1080p frames, sharded by image over the ranks, one launch each ------
         F5 = 512 // world
         step5, oh5, ow5, _, plan5, keep5 = backend.make_warp(F5, 1920, 1080, 5000 + rank)
-        el5, ms5 = timed(backend, step5, 5, 2, sync_all)
+        el5, ms5 = timed(backend, step5, 5, 2, sync_all, PREWARM_MS)
         el5 = max_over_ranks(el5)
         by5 = F5 * 3 * (1080 * 1920 + oh5 * ow5)
         extras["config5_batch_1080p"] = {"workload": "512 frames 1920x1080 RGB u8 -> %dx%d u8, %d per rank in ONE launch (sharded by image, no collective)"
