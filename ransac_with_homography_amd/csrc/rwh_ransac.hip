@@ -473,7 +473,7 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
 // it -- and no faster, because its ~147 SALU instructions per hypothesis (mask bookkeeping and uniform branches per
 // 64-pair word) then fill the CU's one scalar issue slot per clock.  This kernel decides all words of a hypothesis with
 // straight-line code and branches ONCE, to the exact arithmetic, if any pair of the hypothesis is inside its band.
-template <int LOSS, int WORDS, bool MASKS>
+template <int LOSS, int WORDS, bool MASKS, bool CHUNKED = false>
 __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restrict__ hs, const float* __restrict__ pa,
                                                            const float* __restrict__ pb, int m, int k, int hpw, double th,
                                                            float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
@@ -497,6 +497,11 @@ __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restri
         if (h_begin >= k) return;
         h_end = min(k, h_begin + hpw);
     }
+    // CHUNKED (M > 256, one problem): blockIdx.y picks 256 of the correspondences; every chunk's wave adds its part of a
+    // hypothesis' count to counts[] (zeroed by the launcher) and writes its own four mask words -- the points stay in
+    // registers and nothing is re-read per hypothesis, whatever M is
+    const int chunk = CHUNKED ? (int)blockIdx.y : 0;
+    if constexpr (CHUNKED) { pa += 2 * (size_t)(256 * chunk); pb += 2 * (size_t)(256 * chunk); m = min(256, m - 256 * chunk); }
     const int stop_p = stop_keys ? h_begin / k_per : 0;
     const int stop_need = stop_keys ? stop_needs[stop_p] : 0;
     unsigned long long* stop_word = stop_keys ? stop_keys + 2 * (size_t)stop_p + 1 : nullptr;
@@ -525,7 +530,8 @@ __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restri
     };
     float hv = fetch(h_begin);
     int32_t* cnt_out = counts + h_begin;                          // running output positions: no 64-bit multiplies in the loop
-    uint64_t* mask_out = MASKS ? masks + (size_t)h_begin * mask_stride : nullptr;
+    uint64_t* mask_out = MASKS ? masks + (size_t)h_begin * mask_stride + 4 * chunk : nullptr;
+    const int my_words = CHUNKED ? min(4, mask_stride - 4 * chunk) : mask_stride;    // mask words this wave owns per hypothesis
     for (int hyp0 = h_begin; hyp0 < h_end; hyp0 += HB) {
         const float hv_next = fetch(hyp0 + HB);
         const int nb = min(HB, h_end - hyp0);
@@ -547,7 +553,7 @@ __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restri
                 const int local = hyp - stop_p * k_per;
                 if (done != 0ull && (long long)(0xFFFFFFFFull - done) < (long long)local) {      // an earlier hypothesis already exits
                     if (lane == 0) *cnt_out = -1;
-                    if (MASKS && lane < mask_stride) mask_out[lane] = 0;
+                    if (MASKS && lane < my_words) mask_out[lane] = 0;
                     continue;
                 }
             }
@@ -604,10 +610,11 @@ __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restri
                 unsigned long long mine = 0ull;                   // lane w stores word w: one store instruction per hypothesis
 #pragma unroll
                 for (int w = 0; w < WORDS; ++w) mine = lane == w ? inb[w] : mine;
-                if (lane < mask_stride) mask_out[lane] = mine;
+                if (lane < my_words) mask_out[lane] = mine;
             }
             if (lane == 0) {
-                *cnt_out = count;
+                if constexpr (CHUNKED) atomicAdd(cnt_out, count);
+                else *cnt_out = count;
                 if (stop_word && count >= stop_need) atomicMax(stop_word, 0xFFFFFFFFull - (unsigned long long)(hyp - stop_p * k_per));
             }
         }
@@ -787,6 +794,20 @@ void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const f
         }
 #undef RWH_FILTER
         return;
+    }
+    if (filter && !d_err && !offsets && !stop_keys) {     // M > 256, one problem: the same kernel per chunk of 256 correspondences
+        const int chunks = (m + 255) / 256;
+        int hc = (int)((long long)k * chunks / 14000);
+        hc = hc < 1 ? 1 : (hc > 14 ? 14 : hc);
+        if (g_force_score_hpw) hc = g_force_score_hpw;
+        const dim3 cgrid((unsigned)(((k + hc - 1) / hc + 3) / 4), (unsigned)chunks);
+        if (chunks <= 65535 && hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)k, s) == hipSuccess) {
+            if (d_masks) hipLaunchKernelGGL((score_filter_kernel<LOSS, 4, true, true>), cgrid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hc, th,
+                                            sq_limit, d_counts, d_masks, nullptr, 0, mask_stride, nullptr, nullptr, thf);
+            else hipLaunchKernelGGL((score_filter_kernel<LOSS, 4, false, true>), cgrid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hc, th,
+                                    sq_limit, d_counts, d_masks, nullptr, 0, mask_stride, nullptr, nullptr, thf);
+            return;
+        }
     }
 #define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, \
                                         sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride, stop_needs, stop_keys, thf, filter)
