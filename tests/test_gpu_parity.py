@@ -1151,14 +1151,17 @@ def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
     return orc.nearest_neighbor(z_t, img.copy(), bound_hw[0], bound_hw[1], len(ys), len(xs))
 
 
-@pytest.mark.parametrize("block", range(4))
+@pytest.mark.parametrize("block", range(6))
 def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
     """Random homographies (rotation, anisotropic scale 0.6-1.8, shear, perspective, translation), random source and
-    output sizes (narrower and wider than one 128-pixel tile), random patch shape: fast kernels vs the oracle."""
+    output sizes (narrower and wider than one 128-pixel tile), random patch shape: fast kernels vs the oracle.  Blocks 4-5:
+    larger sources whose grids overhang them on every side (border patches: clamped windows, masked taps) and bounds smaller
+    than the source (wrapPerspectiveScan's `res`)."""
     from ransac_with_homography_amd import kernels
     rng = np.random.default_rng(1000 + block)
-    for case in range(10):
-        sh, sw = int(rng.integers(24, 260)), int(rng.integers(24, 420))
+    big = block >= 4
+    for case in range(10 if not big else 6):
+        sh, sw = (int(rng.integers(24, 260)), int(rng.integers(24, 420))) if not big else (int(rng.integers(300, 520)), int(rng.integers(400, 900)))
         img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
         t = rng.uniform(-np.pi, np.pi) if case % 2 else rng.uniform(-0.1, 0.1)
         sx, sy = rng.uniform(0.6, 1.8, 2)
@@ -1168,25 +1171,26 @@ def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
         H[:2, 2] = rng.uniform(-40, 40, 2) + np.array([sw / 2, sh / 2]) - A @ np.array([sw / 2, sh / 2])
         H[2, :2] = rng.uniform(-4e-4, 4e-4, 2)
         inv = np.linalg.inv(H)
-        ow, oh = int(rng.integers(8, 520)), int(rng.integers(5, 300))
-        x0, y0 = rng.uniform(-30, 30, 2)
+        ow, oh = (int(rng.integers(8, 520)), int(rng.integers(5, 300))) if not big else (int(rng.integers(500, 1100)), int(rng.integers(300, 620)))
+        x0, y0 = rng.uniform(-30, 30, 2) if not big else rng.uniform(-90, -20, 2)
         stepx, stepy = rng.uniform(0.7, 1.3, 2)
         xs, ys = x0 + stepx * np.arange(ow), y0 + stepy * np.arange(oh)
         grid = kernels.Grid(xs[0], xs[-1], ow, ys[0], ys[-1], oh)
         xs, ys = np.linspace(xs[0], xs[-1], ow), np.linspace(ys[0], ys[-1], oh)
         shape = [None, "5", "6", "7"][int(rng.integers(0, 4))]
         _force_shape(shape)
-        ref = _oracle_warp_on_grid(img, inv, xs, ys, (sh, sw))
+        bound = (sh, sw) if not (big and case % 2) else (int(rng.integers(sh // 2, sh)), int(rng.integers(sw // 2, sw)))
+        ref = _oracle_warp_on_grid(img, inv, xs, ys, bound)
         src = torch.from_numpy(img).to(gpu)
-        got = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.float32).cpu().numpy()
+        got = kernels.warp_backward(src, inv, grid, bound, "bilinear", torch.float32).cpu().numpy()
         ok = close(got, ref)
         assert (~ok).sum() <= 3, (block, case, shape, (sh, sw), (oh, ow), int((~ok).sum()), float(np.abs(got - ref).max()))
-        u8 = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8).cpu().numpy()
+        u8 = kernels.warp_backward(src, inv, grid, bound, "bilinear", torch.uint8).cpu().numpy()
         d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
         assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (block, case, shape, int((d > 1).sum()), float((d != 0).mean()))
         # nearest neighbour: every pixel equal (index work is bit-exact)
-        nn_ref = _oracle_nn_on_grid(img, inv, xs, ys, (sh, sw))
-        nn = kernels.warp_backward(src, inv, grid, (sh, sw), "nn", torch.uint8).cpu().numpy()
+        nn_ref = _oracle_nn_on_grid(img, inv, xs, ys, bound)
+        nn = kernels.warp_backward(src, inv, grid, bound, "nn", torch.uint8).cpu().numpy()
         assert np.array_equal(nn, nn_ref), (block, case, shape, int((nn != nn_ref).any(axis=2).sum()))
 
 
