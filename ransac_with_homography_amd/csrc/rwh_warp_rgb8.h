@@ -32,7 +32,6 @@
 // No MFMA: there is no dense contraction on this path.
 #pragma once
 #include "rwh_common.h"
-#include <cstddef>
 
 namespace rwh {
 
@@ -61,7 +60,6 @@ struct Coef {
 };
 constexpr int TAB_N = 8;                                 // images per launch when every image has its own homography
 struct CoefTab { Coef e[TAB_N]; };
-typedef const Coef __attribute__((address_space(4))) * CoefK;   // a Coef in kernel-argument (constant) memory
 
 struct FastArgs {
     const unsigned char* src;
@@ -576,14 +574,6 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const unsigned img = a.tiles_y_magic ? __umulhi(t, a.tiles_y_magic) : t;
     const unsigned ty = t - img * a.tiles_y;
     const Coef& co = tab ? tab[img] : a.c;                  // uniform: scalar loads either way
-    // the same coefficients, addressed through the kernel-argument segment with an offset the optimiser cannot see through
-    // (FastArgs is kernel argument 0, the CoefTab of the *_tab kernels argument 1): see run_coords
-    auto late_coef = [&]() __attribute__((always_inline)) -> CoefK {
-        uint32_t off = tab ? (uint32_t)(((sizeof(FastArgs) + 7) & ~size_t(7)) + (size_t)img * sizeof(Coef)) : (uint32_t)offsetof(FastArgs, c);
-        off = __builtin_amdgcn_readfirstlane(off);
-        asm volatile("" : "+s"(off));
-        return (CoefK)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() + off);
-    };
     const unsigned img_mem = tab ? (unsigned)co.image : img;   // where the image lives in the batch
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int lane = threadIdx.x & 63;
@@ -667,14 +657,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     // run h (0: pixels 0..3, 1: pixels 4..7 = columns +PW/2 ..): the three pixels that are not an end pixel share
     // one reciprocal (batch inversion); registers are reused between the runs
     uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
-    // `cf`: where the per-pixel offsets are read from.  The staged path passes `co` itself (scalar registers loaded at
-    // entry); the rare paths pass a pointer the optimiser cannot see through (`late_coef`), so that they re-load the
-    // offsets where they use them instead of keeping ~40 scalar registers alive across the whole kernel -- which made the
-    // compiler spill scalars into VGPR lanes (v_writelane: VALU instructions, in the 94 %-busy unit) on EVERY wave's way in.
-    auto run_coords = [&](const int h, const CoefK cf) __attribute__((always_inline)) {
+    auto run_coords = [&](const int h) {
         double X[3], Y[3], W[3], rc[3];
 #pragma unroll
-        for (int j = 0; j < 3; ++j) { X[j] = X0 + cf->dxs8[3 * h + j][0]; Y[j] = Y0 + cf->dxs8[3 * h + j][1]; W[j] = W0 + cf->dxs8[3 * h + j][2]; }
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + co.dxs8[3 * h + j][0]; Y[j] = Y0 + co.dxs8[3 * h + j][1]; W[j] = W0 + co.dxs8[3 * h + j][2]; }
         const double p12 = W[0] * W[1], P = p12 * W[2];
         if (wpos) {                                                        // finite, normal product of positive W
             double rp = __builtin_amdgcn_rcp(P);
@@ -782,7 +768,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                           // the two runs of 4 pixels: registers are reused
-            run_coords(h, (CoefK)&co);
+            run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 weights(lx[j], ly[j], W_SCALE, W_ONE, wx0[j], wx1[j], wy0[j], wy1[j]);
@@ -885,7 +871,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             unsigned vbits = 0u;
-            run_coords(h, late_coef());
+            run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 const bool valid = pixel_valid(j);
@@ -911,7 +897,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         uint32_t off[FP_PX];
         bool near_end = false;
         unsigned vbits = 0u;
-        run_coords(h, late_coef());
+        run_coords(h);
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j) {
             const bool valid = pixel_valid(j);
