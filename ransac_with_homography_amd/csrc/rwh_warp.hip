@@ -453,12 +453,14 @@ static void fill_offsets(Coef& c, int shape, int pstr) {
 // (variant 2 / `group` / `custom` serve tools/warp_lab.hip: an experimental kernel on the 8 px kernel's 128 x 16 block tiles.)
 int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, double y0, double step_y,
                 int dst_dtype, int batch, hipStream_t s, int variant, int group = 1,
-                void (*custom)(const FastArgs) = nullptr, int n_h = 1, const CompArgs* comp = nullptr) {
+                void (*custom)(const FastArgs) = nullptr, int n_h = 1, const CompArgs* comp = nullptr, int channels = 3) {
     const bool px8 = variant >= 1, nn = variant == 3;
     if (w.out_w < (px8 ? 128 : FP_PX) || w.bound_w > (1 << 19) || w.bound_h > (1 << 19)) return RWH_E_UNSUPPORTED;
     if (n_h != 1 && (!px8 || custom)) return RWH_E_UNSUPPORTED;
+    // 4 channels: the uint8 RGBA form of the 8 px bilinear kernel only (one homography, no compositor)
+    if (channels == 4 && (!px8 || nn || dst_dtype != RWH_U8 || n_h != 1 || comp || custom)) return RWH_E_UNSUPPORTED;
     const size_t dst_esz = dst_dtype == RWH_U8 ? 1 : 4;
-    if ((size_t)w.rows * (size_t)w.out_w * 3 * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
+    if ((size_t)w.rows * (size_t)w.out_w * (size_t)channels * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
     FastArgs a;
     a.src = w.src; a.dst = w.dst; a.src_img_stride = w.src_img_stride; a.dst_img_stride = w.dst_img_stride;
     a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
@@ -505,6 +507,12 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
             else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
             else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
             else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
+        }
+        if (channels == 4) {
+            if (plan_only("rwh::warp_rgba8_fast8<%.0s%d>", "", shape)) return RWH_OK;
+            kern = shape == 7 ? warp_rgba8_fast8<7> : shape == 6 ? warp_rgba8_fast8<6> : warp_rgba8_fast8<5>;
+            hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a);
+            return check_launch();
         }
         if (comp) {      // canvas compositor: the 8 px kernel with the paste / 'Rate' epilogue (uint8, one image)
             if (!px8 || nn || !u8 || batch != 1) return RWH_E_UNSUPPORTED;
@@ -661,6 +669,11 @@ extern "C" int rwh_warp_backward(const void* d_src, int src_h, int src_w, int ch
     if (src_dtype == RWH_U8 && channels == 3 && interp == RWH_BILINEAR && (dst_dtype == RWH_U8 || dst_dtype == RWH_F32)) {
         const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*variant=*/a.out_w >= 128 ? 1 : 0);
         if (st != RWH_E_UNSUPPORTED) return st;  // else: shape outside the fast kernel's limits -> generic kernel
+    }
+
+    if (src_dtype == RWH_U8 && channels == 4 && interp == RWH_BILINEAR && dst_dtype == RWH_U8 && a.out_w >= 128) {
+        const int st = launch_fast(a, inv_h, x0, step_x, y0, step_y, dst_dtype, batch, s, /*variant=*/1, 1, nullptr, 1, nullptr, 4);
+        if (st != RWH_E_UNSUPPORTED) return st;
     }
 
     if (src_dtype == RWH_U8) return channels == 3 ? dispatch<unsigned char, 3>(a, interp, dst_dtype, s)

@@ -32,6 +32,7 @@
 // No MFMA: there is no dense contraction on this path.
 #pragma once
 #include "rwh_common.h"
+#include <type_traits>
 
 namespace rwh {
 
@@ -135,11 +136,11 @@ __device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, floa
 // the group's 4*PSTR pixels are re-dealt so that lane l stores the 16-byte pieces l, PSTR + l, 2*PSTR + l of the
 // group's contiguous 48*PSTR-byte row segment: three fully coalesced dwordx4 stores instead of four 12-byte ones
 // (the texture-address path, 87 % busy on this variant, charges a dwordx3 like a dwordx4).
-template <bool U8>
+template <bool U8, int CH = 3>
 __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                        const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                        const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
-                                       const float (&wy0)[FP_PX], const float (&wy1)[FP_PX], float (&o)[FP_PX][3]) {
+                                       const float (&wy0)[FP_PX], const float (&wy1)[FP_PX], float (&o)[FP_PX][CH]) {
     constexpr float BIAS = U8 ? U8_BIAS : 0.f;
 #pragma unroll
     for (int j = 0; j < FP_PX; j += 2) {
@@ -147,7 +148,7 @@ __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32
         const f2 WY0 = {wy0[j], wy0[j + 1]}, WY1 = {wy1[j], wy1[j + 1]};
         const f2 W00 = WX0 * WY0, W01 = WX1 * WY0, W10 = WX0 * WY1, W11 = WX1 * WY1;
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
+        for (int k = 0; k < CH; ++k) {
             const f2 P00 = {ubyte(a0[j], k), ubyte(a0[j + 1], k)}, P01 = {ubyte(b0[j], k), ubyte(b0[j + 1], k)};
             const f2 P10 = {ubyte(a1[j], k), ubyte(a1[j + 1], k)}, P11 = {ubyte(b1[j], k), ubyte(b1[j + 1], k)};
             f2 acc = __builtin_elementwise_fma(P00, W00, f2{BIAS, BIAS});
@@ -159,7 +160,7 @@ __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32
     }
 }
 
-template <typename DstT, int PSTR = 1>
+template <typename DstT, int PSTR = 1, int CH = 3>
 __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                             const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                             const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
@@ -167,6 +168,29 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
                                             DstT* drow, bool store_any, int shift, unsigned char* xpose = nullptr,
                                             int group = 0, int l = 0) {
     constexpr bool U8 = sizeof(DstT) == 1;
+    if constexpr (CH == 4) {                                  // RGBA uint8: a pixel is one dword, a run 16 bytes
+        static_assert(U8 && PSTR == 1, "the 4-channel form is uint8 in, uint8 out");
+        float o4[FP_PX][4];
+        blend4<true, 4>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o4);
+        if (!store_any) return;
+        uint32_t px[FP_PX];
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            uint32_t q = 0;
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o4[j][0], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o4[j][1], 1, q);
+            q = __builtin_amdgcn_cvt_pk_u8_f32(o4[j][2], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o4[j][3], 3, q);
+            px[j] = q;
+        }
+        if (shift == 0) {
+            const pk4 w = {px[0], px[1], px[2], px[3]};
+            __builtin_memcpy(drow, &w, 16);
+        } else {
+#pragma unroll
+            for (int j = 1; j < FP_PX; ++j)
+                if (j >= shift) __builtin_memcpy(drow + 4 * j, &px[j], 4);
+        }
+        return;
+    }
     float o[FP_PX][3];
     blend4<U8>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
     if (!store_any && !xpose) return;
@@ -548,8 +572,9 @@ template <typename DstT, int LOG_PW> constexpr int f8_waves() {
 // occupancy-sensitive (time ~ 9.5 + 35/n us per 4K frame for n resident waves per SIMD, n <= 5 measured) and this
 // keeps it at 6 waves (LDS-limited).  The end pixels are computed once, so the footprint and the taps can never
 // disagree about a floor().
-template <typename DstT, int LOG_PW, bool COMP = false>
+template <typename DstT, int LOG_PW, bool COMP = false, int CH = 3>
 __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, const CompArgs* cp = nullptr) {
+    static_assert(CH == 3 || (CH == 4 && !COMP && sizeof(DstT) == 1), "4 channels: uint8 RGBA in and out, no compositor");
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
     constexpr int LPR = PW / 8;                             // lanes per patch row
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
@@ -597,8 +622,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;       // uniform
     unsigned char* dimg = a.dst + (long long)img_mem * a.dst_img_stride;              // uniform
     // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
-    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
-    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(CH * sizeof(DstT)));
+    const uint32_t pitch = (uint32_t)a.src_w * (uint32_t)CH;
 
     // ---- compositor: where does this wave's patch lie relative to the rectangles T and Q? (uniform) ---------------------
     bool all_t = true;
@@ -715,15 +740,16 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 
     // ---- staging loads go out now: lane -> (row srow of the pass, chunk scol), fixed for the kernel ---------------------
     unsigned char* my = slab[wave];
-    pk3 v[Win::PASSES];
+    using chunk_t = typename std::conditional<CH == 4, pk4, pk3>::type;   // 4 texels as they lie in memory: 12 or 16 bytes
+    chunk_t v[Win::PASSES];
     // lanes outside the footprint (chunk >= C, or past the last full row of a pass) load nothing: the texture-address
     // path charges per lane (~14 B / clk / CU), and at 79 % busy it was the kernel's second bottleneck
     const int srow = lane / Win::LPRW, scol = lane - srow * Win::LPRW;
     const bool sactive = (srow < Win::RPP) & (scol < C);
     const uint32_t wl = (uint32_t)(srow * Win::LPITCH + scol * 16);               // the lane's slab byte inside a pass
-    const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)scol));
+    const uint32_t goff = mad24_s((uint32_t)srow, pitch, CH == 4 ? (uint32_t)scol << 4 : mul24_12((uint32_t)scol));
     if (staged) {
-        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+        const unsigned char* gbase = simg + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * (uint32_t)CH);   // uniform
 #pragma unroll
         for (int p = 0; p < Win::PASSES; ++p) {
             if (p * Win::RPP < nrows && sactive) {                      // first half uniform: unused passes cost nothing
@@ -731,9 +757,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 // before it already wrote: same bytes to the same place)
                 const int r0 = min(p * Win::RPP, nrows - Win::RPP);
 #ifdef RWH_ABL_NOLOAD   // tools/warp_lab ablation hook (never defined in the product build)
-                v[p] = pk3{goff, goff * 3u, goff * 5u};
+                v[p] = chunk_t{goff, goff * 3u, goff * 5u};
 #else
-                __builtin_memcpy(&v[p], gbase + (size_t)((uint32_t)r0 * pitch) + goff, 12);
+                __builtin_memcpy(&v[p], gbase + (size_t)((uint32_t)r0 * pitch) + goff, sizeof(chunk_t));
 #endif
             }
         }
@@ -755,10 +781,14 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             if (p * Win::RPP < nrows && sactive) {                      // 12 packed bytes -> 4 RGBX texels
                 const int r0 = min(p * Win::RPP, nrows - Win::RPP);
                 uint4 t4;
-                t4.x = v[p].a;
-                t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
-                t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
-                t4.w = v[p].c >> 8;
+                if constexpr (CH == 4) {                      // RGBA texels are slab texels already
+                    t4.x = v[p].a; t4.y = v[p].b; t4.z = v[p].c; t4.w = v[p].d;
+                } else {
+                    t4.x = v[p].a;
+                    t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
+                    t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
+                    t4.w = v[p].c >> 8;
+                }
                 *reinterpret_cast<uint4*>(my + (uint32_t)r0 * lpitch + wl) = t4;
             }
         }
@@ -785,7 +815,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             if constexpr (PSTR > 1) {
                 // float32 output: re-deal through the free upper half of the slab when there is one (uniform)
                 unsigned char* xp = tshift == 0 ? my + Win::SLAB : nullptr;
-                blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                blend_store<DstT, PSTR, CH>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
                                         xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
             } else if constexpr (COMP) {
                 float o[FP_PX][3];
@@ -802,7 +832,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 }
                 comp_store(*cp, o, tin, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
             } else {
-                blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+                blend_store<DstT, PSTR, CH>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
                                         store_any & (first <= 3 * PSTR), max(first, 0));
             }
         }
@@ -830,7 +860,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 for (int c = 0; c < 3; ++c) oz[j][c] = (tin & (1u << j)) ? o[j][c] : U8_BIAS;
             comp_store(*cp, oz, tin & vbits, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
         } else {
-            blend_store<DstT, PSTR>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + 3 * (PW / 2) * h,
+            blend_store<DstT, PSTR, CH>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
                                     store_any & (first <= 3 * PSTR), max(first, 0));
         }
     };
@@ -845,21 +875,25 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     if (border) {
         {   // stage the clamped window with registers of its own (sharing the main path's `v` stretched its live range over
             // both paths and made the compiler spill the staging loads)
-            const unsigned char* gbase = simg + (size_t)((uint32_t)wymn * pitch + (uint32_t)wxmn * 3u);   // uniform
+            const unsigned char* gbase = simg + (size_t)((uint32_t)wymn * pitch + (uint32_t)wxmn * (uint32_t)CH);   // uniform
             const bool bactive = (srow < Win::RPP) & (scol < wC);
-            pk3 vb[Win::PASSES];
+            chunk_t vb[Win::PASSES];
 #pragma unroll
             for (int p = 0; p < Win::PASSES; ++p)
                 if (p * Win::RPP < wnrows && bactive)
-                    __builtin_memcpy(&vb[p], gbase + (size_t)((uint32_t)min(p * Win::RPP, wnrows - Win::RPP) * pitch) + goff, 12);
+                    __builtin_memcpy(&vb[p], gbase + (size_t)((uint32_t)min(p * Win::RPP, wnrows - Win::RPP) * pitch) + goff, sizeof(chunk_t));
 #pragma unroll
             for (int p = 0; p < Win::PASSES; ++p)
                 if (p * Win::RPP < wnrows && bactive) {
                     uint4 t4;
-                    t4.x = vb[p].a;
-                    t4.y = __builtin_amdgcn_alignbyte(vb[p].b, vb[p].a, 3);
-                    t4.z = __builtin_amdgcn_alignbyte(vb[p].c, vb[p].b, 2);
-                    t4.w = vb[p].c >> 8;
+                    if constexpr (CH == 4) {
+                        t4.x = vb[p].a; t4.y = vb[p].b; t4.z = vb[p].c; t4.w = vb[p].d;
+                    } else {
+                        t4.x = vb[p].a;
+                        t4.y = __builtin_amdgcn_alignbyte(vb[p].b, vb[p].a, 3);
+                        t4.z = __builtin_amdgcn_alignbyte(vb[p].c, vb[p].b, 2);
+                        t4.w = vb[p].c >> 8;
+                    }
                     *reinterpret_cast<uint4*>(my + (uint32_t)min(p * Win::RPP, wnrows - Win::RPP) * (uint32_t)Win::LPITCH + wl) = t4;
                 }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -903,7 +937,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             const bool valid = pixel_valid(j);
             const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
             weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
-            off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * 3u : 0u;
+            off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * (uint32_t)CH : 0u;
             near_end |= valid & (iy > a.src_h - 3);
             vbits |= (unsigned)valid << j;
         }
@@ -915,15 +949,22 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             for (int j = 0; j < FP_PX; ++j) {
                 const pk2 r0 = ld8(simg + off[j]);
                 const pk2 r1 = ld8(simg + off[j] + pitch);
-                a0[j] = r0.a; b0[j] = __builtin_amdgcn_alignbyte(r0.b, r0.a, 3);
-                a1[j] = r1.a; b1[j] = __builtin_amdgcn_alignbyte(r1.b, r1.a, 3);
+                if constexpr (CH == 4) { a0[j] = r0.a; b0[j] = r0.b; a1[j] = r1.a; b1[j] = r1.b; }
+                else {
+                    a0[j] = r0.a; b0[j] = __builtin_amdgcn_alignbyte(r0.b, r0.a, 3);
+                    a1[j] = r1.a; b1[j] = __builtin_amdgcn_alignbyte(r1.b, r1.a, 3);
+                }
             }
         } else {  // byte-exact loads, +1 taps clamped to the image (their weight is 0 when clamped)
-            const uint32_t last = (uint32_t)a.src_h * pitch - 3u;
+            const uint32_t last = (uint32_t)a.src_h * pitch - (uint32_t)CH;
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 const uint32_t o00 = off[j];
-                const uint32_t o01 = min(o00 + 3u, last), o10 = min(o00 + pitch, last), o11 = min(o00 + pitch + 3u, last);
+                const uint32_t o01 = min(o00 + (uint32_t)CH, last), o10 = min(o00 + pitch, last), o11 = min(o00 + pitch + (uint32_t)CH, last);
+                if constexpr (CH == 4) {
+                    a0[j] = ld4(simg + o00); b0[j] = ld4(simg + o01); a1[j] = ld4(simg + o10); b1[j] = ld4(simg + o11);
+                    continue;
+                }
                 a0[j] = simg[o00] | (simg[o00 + 1] << 8) | (simg[o00 + 2] << 16);
                 b0[j] = simg[o01] | (simg[o01 + 1] << 8) | (simg[o01 + 2] << 16);
                 a1[j] = simg[o10] | (simg[o10 + 1] << 8) | (simg[o10 + 2] << 16);
@@ -936,6 +977,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 
 template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+// RGBA uint8 in, RGBA uint8 out: 4-byte texels are slab texels as they lie in memory (no RGB -> RGBX expansion), a pixel is
+// one dword and a run one 16-byte store.  (The reference's own 4-channel images are float32: the generic kernel.)
+template <int LOG_PW>
+__global__ __launch_bounds__(256, 6) void warp_rgba8_fast8(const FastArgs a) { fast8_body<unsigned char, LOG_PW, false, 4>(a, nullptr); }
 // canvas compositor form (uint8): the output grid is the canvas, imgQ is composited in the epilogue (CompArgs)
 template <int LOG_PW>
 __global__ __launch_bounds__(256, 6) void warp_rgb8_comp(const FastArgs a, const CompArgs c) { fast8_body<unsigned char, LOG_PW, true>(a, nullptr, &c); }

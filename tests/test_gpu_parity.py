@@ -1194,6 +1194,44 @@ def test_warp_fuzz_vs_oracle(gpu, block, monkeypatch):
         assert np.array_equal(nn, nn_ref), (block, case, shape, int((nn != nn_ref).any(axis=2).sum()))
 
 
+@pytest.mark.parametrize("shape", [None, "5", "6", "7"])
+def test_warp_rgba_u8_staged_vs_oracle(gpu, shape, monkeypatch):
+    """uint8 RGBA images (4-byte texels: staged without the RGB -> RGBX expansion, `warp_rgba8_fast8`): bilinear uint8 output
+    against the oracle on mild, rotated, bordered and ragged geometries, per patch shape; the alpha channel is a channel
+    like the others (homography.py:123-138 with chn == 4)."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(404)
+    _force_shape(shape)
+    for case in range(6):
+        sh, sw = int(rng.integers(150, 420)), int(rng.integers(200, 640))
+        img = rng.integers(0, 256, (sh, sw, 4), dtype=np.uint8)
+        t = [0.01, -0.04, 0.6, 2.4, 0.02, -0.01][case]
+        A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) * rng.uniform(0.9, 1.15)
+        H = np.eye(3); H[:2, :2] = A
+        H[:2, 2] = rng.uniform(-30, 30, 2) + np.array([sw / 2, sh / 2]) - A @ np.array([sw / 2, sh / 2])
+        H[2, :2] = rng.uniform(-1e-4, 1e-4, 2)
+        inv = np.linalg.inv(H)
+        ow, oh = int(rng.integers(128, 700)), int(rng.integers(40, 400))
+        x0, y0 = rng.uniform(-40, 10, 2)
+        xs, ys = x0 + np.arange(ow) * 1.0, y0 + np.arange(oh) * 1.0
+        grid = kernels.Grid(xs[0], xs[-1], ow, ys[0], ys[-1], oh)
+        xs, ys = np.linspace(xs[0], xs[-1], ow), np.linspace(ys[0], ys[-1], oh)
+        bound = (sh, sw) if case % 2 == 0 else (sh - 7, sw - 11)
+        src = torch.from_numpy(img).to(gpu)
+        assert kernels.warp_plan((sh, sw, 4), torch.uint8, inv, grid, bound, "bilinear", torch.uint8).startswith("rwh::warp_rgba8_fast8<")
+        ref = _oracle_warp_on_grid(img, inv, xs, ys, bound)
+        u8 = kernels.warp_backward(src, inv, grid, bound, "bilinear", torch.uint8).cpu().numpy()
+        assert u8.shape == (oh, ow, 4)
+        d = np.abs(u8.astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
+        assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.02, (case, shape, int((d > 1).sum()), float((d != 0).mean()))
+        # batch of two and a row shard agree with the single launch bit for bit
+        both = kernels.warp_backward(torch.stack([src, src]), inv, grid, bound, "bilinear", torch.uint8)
+        assert torch.equal(both[0].cpu(), torch.from_numpy(u8)) and torch.equal(both[1].cpu(), torch.from_numpy(u8))
+        r0, r1 = oh // 3, oh - 5
+        part = kernels.warp_backward(src, inv, grid, bound, "bilinear", torch.uint8, rows=(r0, r1))
+        assert np.array_equal(part.cpu().numpy(), u8[r0:r1])
+
+
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("case", ["mild", "integer_ties", "rot12", "rot45", "persp", "zoom_out", "horizon"])
 def test_nearest_fast_kernel_bit_exact(gpu, case, exact, monkeypatch):
