@@ -712,7 +712,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
     const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
     const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
-    const int hxmn = smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
+    // (RGBA: the window starts on a multiple of 4 texels, so that its 16-byte staging loads are 16-byte aligned whenever
+    //  the rows are -- a misaligned dwordx4 costs the texture-address path about twice an aligned one)
+    const int hxmn = CH == 4 ? (smin(smin(x0, x1), smin(x2, x3)) & ~3) : smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
     const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
@@ -731,7 +733,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     int wxmn = xmn, wymn = ymn, wnrows = nrows, wC = C;
     bool border = false;
     if (!staged & wpos) {
-        const int cx0 = smin(smax(xmn, 0), a.bound_w - 1), cx1 = smin(smax(xmx, 0), a.bound_w - 1);
+        const int cx0 = smin(smax(xmn, 0), a.bound_w - 1) & (CH == 4 ? ~3 : ~0), cx1 = smin(smax(xmx, 0), a.bound_w - 1);
         const int cy0 = smin(smax(ymn, 0), a.bound_h - 1), cy1 = smin(smax(ymx, 0), a.bound_h - 1);
         const int nr = smax(cy1 - cy0 + 2, Win::RPP), nc = (cx1 - cx0 + 5) >> 2;
         border = (nr <= Win::ROWS) & (nc <= Win::LPRW) & (cy0 + nr - 1 <= a.src_h - 2);
