@@ -181,13 +181,20 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             q = __builtin_amdgcn_cvt_pk_u8_f32(o4[j][2], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o4[j][3], 3, q);
             px[j] = q;
         }
-        if (shift == 0) {
-            const pk4 w = {px[0], px[1], px[2], px[3]};
-            __builtin_memcpy(drow, &w, 16);
+        // (an RGBA pixel is 4-byte aligned: said to the compiler, which splits a 16-byte copy to a byte pointer into four
+        //  dword stores -- 6.9 store instructions per wave instead of 2)
+        uint32_t* d32 = reinterpret_cast<uint32_t*>(__builtin_assume_aligned(drow, 4));
+        if (!__any(shift != 0)) {
+            // the whole wave stores whole runs (every tile but a ragged row's last): ONE dwordx4 store, spelled in assembly --
+            // left to itself the compiler folds this branch into the per-pixel predicated stores below (6.9 store
+            // instructions per wave instead of 2: the kernel's time follows them)
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            const u32x4 w = {px[0], px[1], px[2], px[3]};
+            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(d32), "v"(w) : "memory");
         } else {
 #pragma unroll
-            for (int j = 1; j < FP_PX; ++j)
-                if (j >= shift) __builtin_memcpy(drow + 4 * j, &px[j], 4);
+            for (int j = 0; j < FP_PX; ++j)
+                if (j >= shift) d32[j] = px[j];
         }
         return;
     }
@@ -712,9 +719,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
     const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
     const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
-    // (RGBA: the window starts on a multiple of 4 texels, so that its 16-byte staging loads are 16-byte aligned whenever
-    //  the rows are -- a misaligned dwordx4 costs the texture-address path about twice an aligned one)
-    const int hxmn = CH == 4 ? (smin(smin(x0, x1), smin(x2, x3)) & ~3) : smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
+    // (the window starts on a multiple of 4 texels = 12 / 16 bytes, so that the staging loads are dword / 16-byte aligned
+    //  whenever the source rows are)
+    const int hxmn = smin(smin(x0, x1), smin(x2, x3)) & ~3, hxmx = smax(smax(x0, x1), smax(x2, x3));
     const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
@@ -733,7 +740,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     int wxmn = xmn, wymn = ymn, wnrows = nrows, wC = C;
     bool border = false;
     if (!staged & wpos) {
-        const int cx0 = smin(smax(xmn, 0), a.bound_w - 1) & (CH == 4 ? ~3 : ~0), cx1 = smin(smax(xmx, 0), a.bound_w - 1);
+        const int cx0 = smin(smax(xmn, 0), a.bound_w - 1) & ~3, cx1 = smin(smax(xmx, 0), a.bound_w - 1);
         const int cy0 = smin(smax(ymn, 0), a.bound_h - 1), cy1 = smin(smax(ymx, 0), a.bound_h - 1);
         const int nr = smax(cy1 - cy0 + 2, Win::RPP), nc = (cx1 - cx0 + 5) >> 2;
         border = (nr <= Win::ROWS) & (nc <= Win::LPRW) & (cy0 + nr - 1 <= a.src_h - 2);

@@ -17,6 +17,7 @@ dev = _lib.require_gpu()
 g = torch.Generator(device="cpu").manual_seed(1)
 src = torch.randint(0, 256, (frames, Hh, W, 3), dtype=torch.uint8, generator=g).to(dev)
 mx, my, ow, oh = (0, 0, W, Hh) if ("ROT" in os.environ or "SCALE" in os.environ) else hg._bounds(Hh, W, H_S, 0)
+ow = int(os.environ.get("OUTW", ow))          # OUTW=<n>: cut the output grid to n columns (store-alignment experiments)
 grid = kernels.Grid(mx, mx + ow - 1, ow, my, my + oh - 1, oh)
 inv = np.linalg.inv(H_S)
 out = torch.empty((frames, oh, ow, 3), dtype=torch.uint8, device=dev)
