@@ -1111,7 +1111,7 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
     const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
     const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
-    const int hxmn = smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
+    const int hxmn = smin(smin(x0, x1), smin(x2, x3)) & ~3, hxmx = smax(smax(x0, x1), smax(x2, x3));   // window from a multiple of 4 texels
     const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
     const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
     const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
