@@ -8,6 +8,29 @@ basic blocks of the ragged-row stores (the ones holding global_store_byte / glob
 Phases are split at the landmarks the kernel's source has: last staging load, last staging LDS write, first store."""
 import collections, re, sys
 path, sym = sys.argv[1], sys.argv[2]
+if len(sys.argv) > 3 and sys.argv[3] == "--blocks":
+    # per basic block: VALU / SALU / LDS / VMEM / scratch counts (since the border path joined the kernel, the straight-line
+    # walk below no longer isolates the staged path: its two runs are the blocks with 8 LDS reads, 48 byte converts and no
+    # 64-bit compares)
+    text = open(path).read()
+    a = text.index(sym + ":"); b = text.index(".Lfunc_end", a)
+    name, cur, blocks = "entry", [], []
+    for l in text[a:b].split("\n"):
+        l = l.strip()
+        if not l or l.startswith(";"): continue
+        if re.match(r"^\.LBB\d+_\d+:", l):
+            blocks.append((name, cur)); name, cur = l, []
+        else:
+            cur.append(l)
+    blocks.append((name, cur))
+    for name, bl in blocks:
+        c = collections.Counter(m.group(0) for m in (re.match(r"^(v_|s_|ds_|global_|scratch_)\S+", l) for l in bl) if m)
+        n = lambda pre: sum(v for k, v in c.items() if k.startswith(pre))
+        if n("v_") > 10 or n("scratch_"):
+            print("%-12s VALU %3d SALU %3d LDS %2d VMEM %2d scratch %d  byte converts %2d  u64 compares %d  writelane %d" %
+                  (name, n("v_"), n("s_"), n("ds_"), n("global_"), n("scratch_"), sum(v for k, v in c.items() if "cvt_f32_ubyte" in k),
+                   sum(v for k, v in c.items() if "_u64" in k and k.startswith("v_cmp")), c.get("v_writelane_b32", 0)))
+    sys.exit(0)
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
