@@ -567,11 +567,13 @@ inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // h
     return nrows >= 64 / lprw && nrows <= rows && ((ntex + 3) >> 2) <= lprw;
 }
 
-// Waves per SIMD the register allocator must leave room for.  uint8 output: 64 VGPRs (no spills) and 20 160 B of LDS per
-// block -> 8 waves (+2.4 % over 6); 128 x 4 patches 7, 32 x 16 patches 6 (their windows need the LDS).  float32 output (3 KB
-// more LDS per wave for the re-deal) and the compositor: LDS allows 5 (4 for 32 x 16 patches) and 6.
+// Waves per SIMD the register allocator must leave room for.  uint8 output: 7 (73 VGPRs).  The 64-register / 8-wave build
+// of the first half of the round fits only by spilling a dozen scalars into VGPR lanes on the way in; with the border path
+// in the kernel the 7-wave build (72 VGPRs, no spills of either kind) is 0.8 % FASTER in a same-box A/B, and robust.
+// 32 x 16 patches 6 (their windows need the LDS).  float32 output (3 KB more LDS per wave for the re-deal) and the
+// compositor: LDS allows 5 (4 for 32 x 16 patches) and 6.
 template <typename DstT, int LOG_PW> constexpr int f8_waves() {
-    return sizeof(DstT) == 1 ? (LOG_PW == 7 ? 7 : LOG_PW == 5 ? 6 : 8) : (LOG_PW == 5 ? 4 : 5);
+    return sizeof(DstT) == 1 ? (LOG_PW == 7 ? 7 : LOG_PW == 5 ? 6 : 7) : (LOG_PW == 5 ? 4 : 5);
 }
 // Order of work inside a wave: the two END pixels of every lane (own reciprocals) give the footprint and the staging
 // loads go out at once; the other six pixels are computed run by run (3 + 3, one batch inversion each) right before
