@@ -127,6 +127,17 @@ __device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, floa
     wy0 = __builtin_fmaf(-fy, sc, one);
 }
 
+// The 8 px kernels' form (blend4<..., FOLDED = true>): only wx1 = frac_x * 2^32 and wy1 = frac_y * 2^-32 are computed
+// per pixel; the slots wx0 / wy0 carry the pixel's "one" (2^-32, or 0 for a masked pixel) and "one * 2^32" (1 or 0), from
+// which blend4 derives the four tap weights with one multiply, three fused multiply-adds and one subtraction per pixel
+// pair: w11 = fx fy, w01 = fx - w11, w10 = fy - w11, w00 = (1 - fx) - w10  (5.5 instead of 7 VALU instructions per pixel).
+__device__ __forceinline__ void weights2(uint32_t lx, uint32_t ly, float sc, float one, float c1, float& wx0, float& wx1, float& wy0, float& wy1) {
+    wx1 = (float)lx;
+    wy1 = (float)ly * sc;
+    wx0 = one;
+    wy0 = c1;
+}
+
 // Blend 4 pixels (taps a0 = texel(iy,ix), b0 = texel(iy,ix+1), a1/b1 = row iy+1; R,G,B in bytes 0..2)
 // and store them.  `full`: the lane owns all 4 pixels; otherwise it owns local pixels j >= shift.
 // PSTR > 1 (float32 output of the 8 px kernel): the four pixels are PSTR columns apart, pixel j is stored (12 bytes)
@@ -136,7 +147,7 @@ __device__ __forceinline__ void weights(uint32_t lx, uint32_t ly, float sc, floa
 // the group's 4*PSTR pixels are re-dealt so that lane l stores the 16-byte pieces l, PSTR + l, 2*PSTR + l of the
 // group's contiguous 48*PSTR-byte row segment: three fully coalesced dwordx4 stores instead of four 12-byte ones
 // (the texture-address path, 87 % busy on this variant, charges a dwordx3 like a dwordx4).
-template <bool U8, int CH = 3>
+template <bool U8, int CH = 3, bool FOLDED = false>
 __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                        const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                        const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
@@ -146,7 +157,15 @@ __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32
     for (int j = 0; j < FP_PX; j += 2) {
         const f2 WX0 = {wx0[j], wx0[j + 1]}, WX1 = {wx1[j], wx1[j + 1]};
         const f2 WY0 = {wy0[j], wy0[j + 1]}, WY1 = {wy1[j], wy1[j + 1]};
-        const f2 W00 = WX0 * WY0, W01 = WX1 * WY0, W10 = WX0 * WY1, W11 = WX1 * WY1;
+        f2 W00, W01, W10, W11;
+        if constexpr (FOLDED) {              // WX0 = "one", WY0 = "one * 2^32" (see weights2)
+            W11 = WX1 * WY1;
+            W01 = __builtin_elementwise_fma(WX1, WX0, -W11);
+            W10 = __builtin_elementwise_fma(WY1, f2{4294967296.0f, 4294967296.0f}, -W11);
+            W00 = __builtin_elementwise_fma(-WX1, WX0, WY0) - W10;
+        } else {
+            W00 = WX0 * WY0; W01 = WX1 * WY0; W10 = WX0 * WY1; W11 = WX1 * WY1;
+        }
 #pragma unroll
         for (int k = 0; k < CH; ++k) {
             const f2 P00 = {ubyte(a0[j], k), ubyte(a0[j + 1], k)}, P01 = {ubyte(b0[j], k), ubyte(b0[j + 1], k)};
@@ -160,7 +179,7 @@ __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32
     }
 }
 
-template <typename DstT, int PSTR = 1, int CH = 3>
+template <typename DstT, int PSTR = 1, int CH = 3, bool FOLDED = false>
 __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                             const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                             const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
@@ -171,7 +190,7 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
     if constexpr (CH == 4) {                                  // RGBA uint8: a pixel is one dword, a run 16 bytes
         static_assert(U8 && PSTR == 1, "the 4-channel form is uint8 in, uint8 out");
         float o4[FP_PX][4];
-        blend4<true, 4>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o4);
+        blend4<true, 4, FOLDED>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o4);
         if (!store_any) return;
         uint32_t px[FP_PX];
 #pragma unroll
@@ -199,7 +218,7 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
         return;
     }
     float o[FP_PX][3];
-    blend4<U8>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
+    blend4<U8, 3, FOLDED>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
     if (!store_any && !xpose) return;
 #ifdef RWH_ABL_NOSTORE  // tools/warp_lab ablation hook (never defined in the product build)
     if (o[0][0] + o[1][1] + o[2][2] + o[3][0] != -12345.f) return;
@@ -812,7 +831,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
-                weights(lx[j], ly[j], W_SCALE, W_ONE, wx0[j], wx1[j], wy0[j], wy1[j]);
+                weights2(lx[j], ly[j], W_SCALE, W_ONE, 1.0f, wx0[j], wx1[j], wy0[j], wy1[j]);
                 const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
@@ -826,11 +845,11 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             if constexpr (PSTR > 1) {
                 // float32 output: re-deal through the free upper half of the slab when there is one (uniform)
                 unsigned char* xp = tshift == 0 ? my + Win::SLAB : nullptr;
-                blend_store<DstT, PSTR, CH>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
+                blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
                                         xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
             } else if constexpr (COMP) {
                 float o[FP_PX][3];
-                blend4<true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
+                blend4<true, 3, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
                 uint32_t q[FP_PX];
                 const int cx = c0p + (PW / 2) * h;
                 const unsigned qin = comp_load_q(*cp, cy, cx, q);
@@ -843,7 +862,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 }
                 comp_store(*cp, o, tin, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
             } else {
-                blend_store<DstT, PSTR, CH>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
+                blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
                                         store_any & (first <= 3 * PSTR), max(first, 0));
             }
         }
@@ -855,7 +874,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         const int first = tshift - (lcol + (PW / 2) * h);
         if constexpr (COMP) {
             float o[FP_PX][3];
-            blend4<true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
+            blend4<true, 3, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
             uint32_t q[FP_PX];
             const int cx = c0p + (PW / 2) * h;
             const unsigned qin = comp_load_q(*cp, cy, cx, q);
@@ -871,7 +890,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 for (int c = 0; c < 3; ++c) oz[j][c] = (tin & (1u << j)) ? o[j][c] : U8_BIAS;
             comp_store(*cp, oz, tin & vbits, qin, q, reinterpret_cast<unsigned char*>(drow) + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
         } else {
-            blend_store<DstT, PSTR, CH>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
+            blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
                                     store_any & (first <= 3 * PSTR), max(first, 0));
         }
     };
@@ -920,7 +939,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 const bool valid = pixel_valid(j);
-                weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
+                weights2(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, valid ? 1.0f : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
                 vbits |= (unsigned)valid << j;
                 // window-relative texel, kept inside the window whatever the coordinate is: a pixel outside the source has
                 // zero weights, and a valid one lies in the window by convexity (up to a floor() that rounding moved across
@@ -947,7 +966,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         for (int j = 0; j < FP_PX; ++j) {
             const bool valid = pixel_valid(j);
             const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
-            weights(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
+            weights2(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, valid ? 1.0f : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
             off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * (uint32_t)CH : 0u;
             near_end |= valid & (iy > a.src_h - 3);
             vbits |= (unsigned)valid << j;
