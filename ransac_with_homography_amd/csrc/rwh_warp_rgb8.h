@@ -209,7 +209,10 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
             // instructions per wave instead of 2: the kernel's time follows them)
             typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
             const u32x4 w = {px[0], px[1], px[2], px[3]};
-            asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(d32), "v"(w) : "memory");
+            // s_nop: a VMEM store of more than 8 bytes reads its data registers over two cycles, and the next VALU
+            // instruction must not overwrite them in that window -- the compiler pads its own stores, not an asm statement's
+            // (without it, the first two pixels of a run came out as whatever the next instruction wrote: tools/soak_warp.py CH=4)
+            asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 2" : : "v"(d32), "v"(w) : "memory");
         } else {
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j)

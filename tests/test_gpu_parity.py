@@ -1230,6 +1230,20 @@ def test_warp_rgba_u8_staged_vs_oracle(gpu, shape, monkeypatch):
         r0, r1 = oh // 3, oh - 5
         part = kernels.warp_backward(src, inv, grid, bound, "bilinear", torch.uint8, rows=(r0, r1))
         assert np.array_equal(part.cpu().numpy(), u8[r0:r1])
+    # a grid that overhangs the source by 150 px on every side: whole patches outside it (the kernel's whole-run store is an
+    # assembly dwordx4 -- a missing wait state after it once left the first two pixels of such runs to the next instruction:
+    # found by tools/soak_warp.py CH=4) -- against the exact float64 kernel
+    rng = np.random.default_rng(405)
+    for t in (0.02, -0.9, 2.03):
+        img = torch.from_numpy(rng.integers(0, 256, (500, 700, 4), dtype=np.uint8)).to(gpu)
+        A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]])
+        H = np.eye(3); H[:2, :2] = A; H[:2, 2] = np.array([350.0, 250.0]) - A @ np.array([350.0, 250.0]); H[2, :2] = (3e-5, -2e-5)
+        inv = np.linalg.inv(H)
+        grid = kernels.Grid(-150.0, 849.0, 1000, -150.0, 649.0, 800)
+        ex = kernels.warp_backward(img, inv, grid, (500, 700), "bilinear", torch.float64, exact=True)
+        u8 = kernels.warp_backward(img, inv, grid, (500, 700), "bilinear", torch.uint8)
+        d = (u8.to(torch.int16) - ex.to(torch.uint8).to(torch.int16)).abs()
+        assert int((d > 1).sum()) == 0 and float((d != 0).float().mean()) < 0.02, (shape, t, int((d > 1).sum()))
 
 
 @pytest.mark.parametrize("exact", [False, True])

@@ -1,6 +1,6 @@
 """Developer soak test (not part of the suite): the fast warp kernels against the exact float64 kernel (itself pinned
 bit for bit to the reference by the golden tests) on many random homographies, sizes, grids and patch shapes.
-   python tools/soak_warp.py [cases] [seed]"""
+   python tools/soak_warp.py [cases] [seed]        CH=4: uint8 RGBA images (the staged RGBA kernel / the generic kernel)"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,11 +8,12 @@ from ransac_with_homography_amd import _lib, kernels
 dev = _lib.require_gpu()
 lib = _lib.load()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+CH = int(os.environ.get("CH", "3"))
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = [0.0, 0, 0.0]
 for case in range(cases):
     sh, sw = int(rng.integers(40, 1400)), int(rng.integers(40, 2000))
-    img = torch.randint(0, 256, (sh, sw, 3), dtype=torch.uint8, device=dev)
+    img = torch.randint(0, 256, (sh, sw, CH), dtype=torch.uint8, device=dev)
     t = rng.uniform(-np.pi, np.pi) if case % 3 == 0 else rng.uniform(-0.08, 0.08)
     sx, sy = rng.uniform(0.5, 2.2, 2) if case % 5 == 0 else rng.uniform(0.85, 1.2, 2)
     A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.array([[sx, rng.uniform(-0.15, 0.15)], [0, sy]])
@@ -40,6 +41,10 @@ for case in range(cases):
     nn_bad = int((nn_e != nn_f).any(dim=2).sum())
     worst = [max(worst[0], float(rel.max())), max(worst[1], big), max(worst[2], float((d != 0).float().mean()))]
     flag = "" if (bad <= 6 and big <= 6 and nn_bad == 0) else "   <-- LOOK"
+    if big > 6:      # where are they?
+        ys_, xs_ = torch.nonzero((d > 1).any(dim=2), as_tuple=True)
+        flag += "  bad u8 pixels: rows %d..%d cols %d..%d (distinct rows %d, cols %d) max|d| %d  bound %s" % (
+            int(ys_.min()), int(ys_.max()), int(xs_.min()), int(xs_.max()), len(torch.unique(ys_)), len(torch.unique(xs_)), int(d.max()), bound)
     if flag or case % 20 == 0:
         print("case %3d src %4dx%-4d out %4dx%-4d shape %d rot %+.2f  f32: %d px > 1e-4 (max rel %.2e)  u8: %d px > 1 LSB, %.4f differ  nn: %d differ%s"
               % (case, sw, sh, ow, oh, shape, t, bad, float(rel.max()), big, float((d != 0).float().mean()), nn_bad, flag), flush=True)
