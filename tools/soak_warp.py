@@ -9,11 +9,13 @@ dev = _lib.require_gpu()
 lib = _lib.load()
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 CH = int(os.environ.get("CH", "3"))
+F32 = os.environ.get("SRC", "u8") == "f32"      # SRC=f32: float32 source images (the generic kernel, one pixel per lane)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
 worst = [0.0, 0, 0.0]
 for case in range(cases):
     sh, sw = int(rng.integers(40, 1400)), int(rng.integers(40, 2000))
     img = torch.randint(0, 256, (sh, sw, CH), dtype=torch.uint8, device=dev)
+    if F32: img = img.float() * 0.37 + 0.11
     t = rng.uniform(-np.pi, np.pi) if case % 3 == 0 else rng.uniform(-0.08, 0.08)
     sx, sy = rng.uniform(0.5, 2.2, 2) if case % 5 == 0 else rng.uniform(0.85, 1.2, 2)
     A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.array([[sx, rng.uniform(-0.15, 0.15)], [0, sy]])
@@ -30,14 +32,14 @@ for case in range(cases):
     assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, shape) == 0
     ex = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.float64, zero_origin=False, exact=True)
     f32 = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.float32, zero_origin=False)
-    u8 = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.uint8, zero_origin=False)
+    u8 = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.uint8, zero_origin=False) if not F32 else ex.clamp(0, 255).to(torch.uint8)
     err = (f32.double() - ex).abs()
     rel = err / ex.abs().clamp(min=1.0)
     bad = int((rel > 1e-4).sum())                      # pixels on a mask edge band may differ (documented): count them
     d = (u8.to(torch.int16) - ex.to(torch.uint8).to(torch.int16)).abs()
     big = int((d > 1).sum())
-    nn_e = kernels.warp_backward(img, inv, grid, bound, "nn", torch.uint8, zero_origin=False, exact=True)
-    nn_f = kernels.warp_backward(img, inv, grid, bound, "nn", torch.uint8, zero_origin=False)
+    nn_e = kernels.warp_backward(img, inv, grid, bound, "nn", img.dtype, zero_origin=False, exact=True)
+    nn_f = kernels.warp_backward(img, inv, grid, bound, "nn", img.dtype, zero_origin=False)
     nn_bad = int((nn_e != nn_f).any(dim=2).sum())
     worst = [max(worst[0], float(rel.max())), max(worst[1], big), max(worst[2], float((d != 0).float().mean()))]
     flag = "" if (bad <= 6 and big <= 6 and nn_bad == 0) else "   <-- LOOK"
