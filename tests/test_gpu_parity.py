@@ -1246,6 +1246,42 @@ def test_warp_rgba_u8_staged_vs_oracle(gpu, shape, monkeypatch):
         assert int((d > 1).sum()) == 0 and float((d != 0).float().mean()) < 0.02, (shape, t, int((d > 1).sum()))
 
 
+@pytest.mark.parametrize("chn", [3, 4])
+def test_warp_fast_kernels_vs_exact_kernel_random_geometries(gpu, chn, monkeypatch):
+    """A short run of tools/soak_warp.py inside the suite: the fast kernels (staged RGB / RGBA bilinear uint8 and float32,
+    nearest neighbour) against the exact float64 kernel -- itself pinned bit for bit to the reference by the goldens -- on
+    random source sizes up to 1400 x 2000, rotations, zooms 0.5-2.2, horizons inside the grid, overhanging grids, scan-mode
+    bounds and every patch shape.  (The soak found what the targeted tests had missed: a missing wait state after an
+    assembly store that garbled two pixels of some runs.)"""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(9000 + chn)
+    for case in range(14):
+        sh, sw = int(rng.integers(40, 1400)), int(rng.integers(40, 2000))
+        img = torch.from_numpy(rng.integers(0, 256, (sh, sw, chn), dtype=np.uint8)).to(gpu)
+        t = rng.uniform(-np.pi, np.pi) if case % 3 == 0 else rng.uniform(-0.08, 0.08)
+        sx, sy = rng.uniform(0.5, 2.2, 2) if case % 5 == 0 else rng.uniform(0.85, 1.2, 2)
+        A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.array([[sx, rng.uniform(-0.15, 0.15)], [0, sy]])
+        H = np.eye(3); H[:2, :2] = A
+        H[:2, 2] = rng.uniform(-60, 60, 2) + np.array([sw / 2, sh / 2]) - A @ np.array([sw / 2, sh / 2])
+        H[2, :2] = rng.uniform(-2e-4, 2e-4, 2) if case % 7 else rng.uniform(-2e-3, 2e-3, 2)
+        inv = np.linalg.inv(H)
+        ow, oh = int(rng.integers(8, 2300)), int(rng.integers(5, 1500))
+        x0, y0 = rng.uniform(-120, 60, 2)
+        stepx, stepy = rng.uniform(0.8, 1.25, 2)
+        grid = kernels.Grid(x0, x0 + stepx * (ow - 1), ow, y0, y0 + stepy * (oh - 1), oh)
+        bound = (sh, sw) if case % 4 else (int(rng.integers(sh // 2, sh + 1)), int(rng.integers(sw // 2, sw + 1)))
+        _force_shape([None, None, "5", "6", "7"][int(rng.integers(0, 5))])
+        ex = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.float64, zero_origin=False, exact=True)
+        f32 = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.float32, zero_origin=False)
+        u8 = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.uint8, zero_origin=False)
+        rel = (f32.double() - ex).abs() / ex.abs().clamp(min=1.0)
+        d = (u8.to(torch.int16) - ex.to(torch.uint8).to(torch.int16)).abs()
+        assert int((rel > 1e-4).sum()) <= 6 and int((d > 1).sum()) <= 6, (chn, case, int((rel > 1e-4).sum()), int((d > 1).sum()))
+        nn_e = kernels.warp_backward(img, inv, grid, bound, "nn", torch.uint8, zero_origin=False, exact=True)
+        nn_f = kernels.warp_backward(img, inv, grid, bound, "nn", torch.uint8, zero_origin=False)
+        assert torch.equal(nn_e, nn_f), (chn, case)
+
+
 @pytest.mark.parametrize("exact", [False, True])
 @pytest.mark.parametrize("case", ["mild", "integer_ties", "rot12", "rot45", "persp", "zoom_out", "horizon"])
 def test_nearest_fast_kernel_bit_exact(gpu, case, exact, monkeypatch):
