@@ -717,6 +717,45 @@ def test_scorer_filter_never_changes_a_decision(gpu):
                     assert np.array_equal(bits, want), (M, method, th, i)
 
 
+def test_scorer_filter_random_problems(gpu):
+    """A short run of tools/soak_ransac.py inside the suite: filter kernels (registers / chunked) against the all-exact scorer
+    on random problems -- sizes 5 ... 3000, coordinate scales 50 ... 1e5, thresholds 0.05 ... 40, all losses, single and
+    batched entry points: counts, masks and packed keys identical."""
+    from ransac_with_homography_amd import kernels, _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(31)
+    for case in range(24):
+        M = int(rng.choice([5, 64, 65, 185, 256, 257, 700, 3000]))
+        scale = float(rng.choice([50.0, 1200.0, 8000.0, 1e5]))
+        Hs = np.array([[rng.uniform(0.7, 1.3), rng.uniform(-0.2, 0.2), rng.uniform(-50, 50)], [rng.uniform(-0.2, 0.2), rng.uniform(0.7, 1.3), rng.uniform(-50, 50)],
+                       [rng.uniform(-1e-5, 1e-5), rng.uniform(-1e-5, 1e-5), 1.0]])
+        A = rng.uniform(0, scale, (M, 2))
+        P = np.c_[A, np.ones(M)] @ Hs.T
+        B = P[:, :2] / P[:, 2:] + rng.normal(0, rng.uniform(0.1, 3.0), (M, 2))
+        out = rng.random(M) < rng.uniform(0.1, 0.7)
+        B[out] = rng.uniform(0, scale, (int(out.sum()), 2))
+        pa, pb = torch.from_numpy(A.astype(np.float32)).to(gpu), torch.from_numpy(B.astype(np.float32)).to(gpu)
+        K = int(rng.choice([7, 500, 3000]))
+        idx = torch.from_numpy(rng.integers(0, M, (K, 4)).astype(np.int32)).to(gpu)
+        th = float(rng.choice([0.05, 1.0, 3.0, 5.0, 40.0]))
+        need = kernels.need_count(M, int(rng.integers(30, 95)), 4)
+        for method in ("fwd", "backward", "reproj"):
+            res = {}
+            for exact in (1, 0):
+                assert lib.rwh_lab_tune(_lib.RWH_TUNE_SCORE_EXACT, exact) == 0
+                try:
+                    ws = kernels.SearchWorkspace(K, M, gpu)
+                    kernels.ransac_search(pa, pb, idx, th, method, need, ws)
+                    bws = kernels.BatchWorkspace(2, K, M, gpu)
+                    kernels.ransac_batched(torch.cat([pa, pa]), torch.cat([pb, pb]), torch.tensor([0, M, 2 * M], dtype=torch.int32, device=gpu),
+                                           torch.tensor([need, need], dtype=torch.int32, device=gpu), th, method, bws, idx=torch.stack([idx, idx]))
+                finally:
+                    lib.rwh_lab_tune(_lib.RWH_TUNE_SCORE_EXACT, 0)
+                res[exact] = [ws.counts.clone(), ws.masks.clone(), ws.best.clone(), bws.counts.clone(), bws.masks.clone(), bws.best.clone()]
+            assert all(torch.equal(a, b) for a, b in zip(res[0], res[1])), (case, M, K, th, scale, method)
+            assert torch.equal(res[0][3][0], res[0][0]) and torch.equal(res[0][3][1], res[0][0]), (case, method)
+
+
 @pytest.mark.parametrize("M", [64, 65, 256, 257, 1000, 1024, 16384])
 def test_scorer_any_number_of_correspondences(gpu, M):
     """SURVEY 8d scaling set: synthetic correspondences (Hs-projected uniform points + 1 px noise + 40 % outliers).
