@@ -158,8 +158,13 @@ RWH_API int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m,
  *   computeLoss(X, Y, method)           ransac.py:182 -> 84-98 (fwd 55-64, reproj 66-76, dist 78-82)
  *   inliers_pos = err < th ; np.sum     ransac.py:183-184
  * and the accept rules of ransac.py:186-202 in order-independent form.
- * One wavefront scores one hypothesis: lanes stride over the M correspondences,
- * `err < th` is ballotted and popcounted.
+ * One wavefront scores a run of consecutive hypotheses: lanes stride over the M
+ * correspondences (kept in registers; M > 256: one wavefront per chunk of 256, counts
+ * accumulated with integer atomic adds after a memset node), `err < th` is ballotted and
+ * popcounted.  A pair whose distance clears `th` by a proven error band is decided from a
+ * reciprocal; a hypothesis with any pair inside the band (or a NaN) is redone with the
+ * reference's two IEEE float32 divisions: counts and masks are bit-identical to the
+ * reference's arithmetic either way.
  * d_counts: K int32.  d_masks: optional (may be NULL) K x ceil(M/64) uint64
  * inlier bitmasks (bit j of word w = correspondence 64*w + j).
  * d_best: 2 x uint64, accumulated with atomic max, so several calls (hypothesis
