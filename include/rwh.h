@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define RWH_ABI_VERSION 1
+#define RWH_ABI_VERSION 2   /* 2: blend modes of rwh_stitch_panorama, RWH_BATCH_EARLY_STOP (d_counts may hold -1), rwh_lab_clock_probe, RWH_HYP_ILLCOND */
 #define RWH_API __attribute__((visibility("default")))
 
 enum {
@@ -61,6 +61,14 @@ RWH_API const char* rwh_strerror(int code);
  */
 enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1, RWH_TUNE_SCORE_EXACT = 2 };
 RWH_API int rwh_lab_tune(int knob, int value);
+
+/*
+ * Lab / measurement hook, not part of the data path: ONE wavefront that stays resident for `milliseconds` (<= 2000) of
+ * the 100 MHz constant clock and then writes d_out[0] = shader-clock cycles elapsed (s_memtime), d_out[1] = 100 MHz ticks
+ * elapsed (s_memrealtime).  Launched on a side stream beside the kernels being timed, d_out[0] / d_out[1] * 100 MHz is the
+ * shader clock the chip held under that load (bench.py: roofline.sclk_mhz).  d_out: 2 x uint64 on the device.
+ */
+RWH_API int rwh_lab_clock_probe(uint64_t* d_out, double milliseconds, void* stream);
 
 /*
  * Backward perspective warp.  Replaces, per call, the body of
@@ -142,12 +150,17 @@ RWH_API int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, int
  * legacy generator for parity, ransac.py:177);
  * d_h: K x 9 float32, row-major 3x3 with h[8] == 1;
  * d_flags: K bytes, bit 0 = repeated index in the sample, bit 1 = non-finite
- * result (singular system).  The 8x9 system is built from float32-rounded
+ * result (singular system), bit 2 = ill-conditioned sample (RWH_HYP_ILLCOND below).  The 8x9 system is built from float32-rounded
  * products like the reference, solved in float64, scaled to unit norm, rounded
  * to float32 and divided by its 9th element in float32.
  */
 #define RWH_HYP_REPEATED 1u
 #define RWH_HYP_SINGULAR 2u
+#define RWH_HYP_ILLCOND 4u   /* bit 2: ill-conditioned sample -- a pivot of the elimination below 1e-3 of its column's scale
+                                (three collinear source points, equal coordinates at different indices, ...) or a unit null
+                                vector whose 9th element is below 1e-7: H is finite but K1's elimination and LAPACK's SVD
+                                (the reference's solver) may round to different float32 H.  RANSAC.run re-derives flagged
+                                samples on the host with the reference's own solver; ~2 % of the samples on natural matches. */
 RWH_API int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m,
                      const int32_t* d_idx, int k,
                      float* d_h, uint8_t* d_flags, void* stream);
@@ -241,6 +254,21 @@ RWH_API int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, const
                        int m_max, int k, int32_t* d_idx, uint64_t seed, int64_t problem_base, double th, int loss,
                        const int32_t* d_need, float* d_h, uint8_t* d_flags, int32_t* d_counts,
                        uint64_t* d_masks, uint64_t* d_best, unsigned flags, void* stream);
+
+/*
+ * HOST helper of the settle step (no device work, no stream): the reference's own 4-point solve for n samples,
+ *   calc_corresp (homography.py:4-14: 8 x 9 float32 DLT matrix, float32 products) -> numpy.linalg.svd (LAPACK dgesdd,
+ *   float64 inside) -> last row of V^T cast to float32 -> / its 9th element in float32   (homography.py:71-88),
+ * on `threads` host threads.  pts_a / pts_b: m x 2 float32 HOST arrays; idx_rows: n x 4 int32 (HOST); out_h: n x 9 float32.
+ * dgesdd_ilp64: address of the Fortran symbol dgesdd (64-bit integers) of the LAPACK the caller's numpy uses
+ * (numpy >= 2: `scipy_dgesdd_64_` in numpy.libs/libscipy_openblas64_*.so): called with numpy's own arguments, so every H is
+ * numpy.linalg.svd's bit for bit -- this entry point only moves the loop off the Python interpreter and onto several
+ * cores.  The accept rules of RANSAC.run need this solver (LAPACK's null vector of a rank-deficient sample is arbitrary
+ * but is what the reference uses, ransac.py:177-180) for samples K1 flags and for hypotheses near the decision.
+ * Returns RWH_E_LAUNCH if LAPACK reported info != 0 for a sample (numpy would raise LinAlgError).
+ */
+RWH_API int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, const int32_t* idx_rows, int n,
+                      void* dgesdd_ilp64, int threads, float* out_h);
 
 /*
  * Fused panorama compositor.  Replaces the body of stitchPanorama (homography.py:288-338) after its canvas

@@ -84,8 +84,14 @@ def calc_homography(u, v, collective=False):
     """DLT: last right-singular vector of the 2N x 9 matrix, divided by its 9th
     element.  numpy.linalg.svd computes in float64 and casts the factors back to
     the float32 of its input, so the result is float32.  homography.py:71-88.
-    `collective` only selects between two builders that produce the same matrix.
+    Non-collective: the 4-point builder reads rows 0..3 only (homography.py:4-14) -- an n-point sample with n > 4
+    (HomoModel(n=6)) is fitted on its first four pairs, and n < 4 raises IndexError like `u[3,0]` does there;
+    collective: all N pairs (homography.py:30-46).
     """
+    if not collective:
+        if u.shape[0] < 4:
+            raise IndexError("index 3 is out of bounds for axis 0 with size %d" % u.shape[0])
+        u, v = u[:4], v[:4]
     mat = dlt_matrix(u, v)
     _, _, vt = np.linalg.svd(mat)
     h = vt[-1].reshape(3, 3)

@@ -1,0 +1,38 @@
+"""The LAPACK numpy itself links, by address (for rwh_host_dlt4_svd, include/rwh.h).
+
+`numpy.linalg.svd` is `dgesdd` of the OpenBLAS bundled with the numpy wheel.  The settle step of `RANSAC.run` needs
+exactly that routine's results (LAPACK's null vector of a rank-deficient 8 x 9 system is arbitrary, and it is what the
+reference uses), but calling it through numpy costs ~11 us per 8 x 9 matrix under the interpreter lock.  `dgesdd_address()`
+returns the address of the same symbol in the library numpy has already loaded, so that the native loop in librwh_hip.so
+can call it from several threads; None if it cannot be found (other numpy builds): callers then stay on numpy.linalg.svd,
+which gives the same numbers, only slower."""
+import ctypes
+import os
+
+_addr = False
+
+
+def dgesdd_address():
+    global _addr
+    if _addr is not False:
+        return _addr
+    _addr = None
+    try:
+        import numpy.linalg._umath_linalg  # noqa: F401  (maps numpy's LAPACK into the process)
+        paths = set()
+        with open("/proc/self/maps") as f:
+            for line in f:
+                p = line.rsplit(" ", 1)[-1].strip()
+                if "openblas" in os.path.basename(p) and "numpy" in p:
+                    paths.add(p)
+        for p in sorted(paths):
+            lib = ctypes.CDLL(p)                       # already loaded: same handle, same code
+            for name in ("scipy_dgesdd_64_", "dgesdd_64_"):     # ILP64 builds only (the helper passes 64-bit integers)
+                try:
+                    _addr = ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+                    return _addr
+                except AttributeError:
+                    continue
+    except Exception:
+        _addr = None
+    return _addr

@@ -10,20 +10,22 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librwh_hip.so")
 
+ABI_VERSION = 2          # RWH_ABI_VERSION of the include/rwh.h this binding was written against
 RWH_U8, RWH_F32, RWH_F64 = 0, 1, 2
 RWH_NEAREST, RWH_BILINEAR = 0, 1
 RWH_LOSS = {"fwd": 0, "backward": 1, "reproj": 2}
 RWH_WARP_ZERO_ORIGIN = 1
 RWH_WARP_EXACT = 2
 RWH_STITCH_FAST = 4
-RWH_HYP_REPEATED, RWH_HYP_SINGULAR = 1, 2
+RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND = 1, 2, 4
 RWH_BATCH_DEVICE_SAMPLING = 1
 RWH_BATCH_EARLY_STOP = 2
 RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT = 0, 1, 2
 
 # every symbol include/rwh.h declares (tests check the library exports them all)
-EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
-           "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama")
+EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
+           "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama",
+           "rwh_host_dlt4_svd")
 
 
 class RwhUnavailable(RuntimeError):
@@ -46,6 +48,8 @@ def _bind(lib):
     lib.rwh_strerror.argtypes = [i32]
     lib.rwh_lab_tune.restype = i32
     lib.rwh_lab_tune.argtypes = [i32, i32]
+    lib.rwh_lab_clock_probe.restype = i32
+    lib.rwh_lab_clock_probe.argtypes = [vp, f64, vp]
     lib.rwh_warp_backward.restype = i32
     lib.rwh_warp_backward.argtypes = [vp, i32, i32, i32, i32, i64, i32,        # src, h, w, c, dtype, stride, batch
                                       c.POINTER(f64), i32,                    # inv_h, n_h
@@ -72,6 +76,8 @@ def _bind(lib):
     lib.rwh_project_points_ex.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.rwh_project_points.restype = i32
     lib.rwh_project_points.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.rwh_host_dlt4_svd.restype = i32
+    lib.rwh_host_dlt4_svd.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
     return lib
 
 
@@ -90,8 +96,11 @@ def load():
             _lib = _bind(ctypes.CDLL(LIB_PATH))
         except OSError as e:
             raise RwhUnavailable("cannot load %s: %s" % (LIB_PATH, e)) from e
-        if _lib.rwh_abi_version() != 1:
-            raise RwhUnavailable("librwh_hip.so ABI version mismatch")
+        if _lib.rwh_abi_version() != ABI_VERSION:
+            got = _lib.rwh_abi_version()
+            _lib = None
+            raise RwhUnavailable("librwh_hip.so reports ABI version %d, this package binds version %d: rebuild it "
+                                 "(`make -C ransac_with_homography_amd/csrc`)" % (got, ABI_VERSION))
     return _lib
 
 

@@ -83,6 +83,18 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
         M[i][6] = (double)(x * yp);  M[i][7] = (double)(y * yp);  M[i][8] = -(double)yp;
     }
 
+    // Conditioning flag (RWH_HYP_ILLCOND): the smallest pivot of the elimination against the scale of its column.  Samples with
+    // three collinear source points, or equal coordinates at different indices, are finite here but arbitrary -- K1's
+    // elimination and LAPACK's SVD then return DIFFERENT float32 H (inlier counts apart by hundreds on lattice-like data) --
+    // and so is any sample whose unit null vector has a 9th element below 1e-7 (h / h[8] amplifies round-off).  The host
+    // settles flagged samples with the reference's own solver (ransac._settle_on_host).  Thresholds: tools/README (k1 calibration).
+    double cs0 = 0.0, cs1 = 0.0, qs = 0.0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        cs0 = fmax(cs0, fabs(M[i][0])); cs1 = fmax(cs1, fabs(M[i][1]));
+        qs = fmax(fmax(qs, fmax(fabs(M[i][3]), fabs(M[i][4]))), fmax(fabs(M[i][6]), fabs(M[i][7])));
+    }
+    double piv_ratio[5];
     // eliminate the shared 4x3 block with partial pivoting (first maximum wins)
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
@@ -99,6 +111,7 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
 #pragma unroll
             for (int j = c; j < 9; ++j) swap_if(sw, M[c][j], M[i][j]);
         }
+        piv_ratio[c] = fabs(M[c][c]) / (c == 0 ? cs0 : c == 1 ? cs1 : 1.0);
         const double rpiv = recip(M[c][c]);
 #pragma unroll
         for (int i = c + 1; i < 4; ++i) {
@@ -115,6 +128,8 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     const double ra11 = recip(a11);
     const double f2 = a21 * ra11;
     const double d2 = a22 - f2 * a12;
+    piv_ratio[3] = fabs(a11) / qs;
+    piv_ratio[4] = fabs(d2) / (fabs(a22) + fabs(f2 * a12));
     const double h8 = (b2 - f2 * b1) * recip(d2);
     const double h7 = (b1 - a12 * h8) * ra11;
 
@@ -136,6 +151,10 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     double ss = 0.0;
 #pragma unroll
     for (int i = 0; i < 9; ++i) ss = ss + h[i] * h[i];
+    // !(x >= t) also catches NaN (0 / 0 scales, inf - inf)
+    bool illcond = !(ss <= 1e14);                             // |n[8]| = 1 / sqrt(ss) < 1e-7
+#pragma unroll
+    for (int i = 0; i < 5; ++i) illcond |= !(piv_ratio[i] >= 1e-3);
     const double rnrm = recip(sqrt(ss));
     float n[9];
 #pragma unroll
@@ -147,7 +166,8 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
         finite &= (fabsf(v) <= 3.4028234664e38f);  // false for NaN / inf
         hstage[9 * threadIdx.x + i] = v;
     }
-    if (live) flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR));
+    if (live) flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR) |
+                                   (illcond ? RWH_HYP_ILLCOND : 0u));
     // the wave's 64 x 9 floats leave as 9 coalesced 256-byte stores (lane-strided 36-byte records would be 9 scattered ones)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();

@@ -147,6 +147,34 @@ __device__ __forceinline__ void weights2(uint32_t lx, uint32_t ly, float sc, flo
 // the group's 4*PSTR pixels are re-dealt so that lane l stores the 16-byte pieces l, PSTR + l, 2*PSTR + l of the
 // group's contiguous 48*PSTR-byte row segment: three fully coalesced dwordx4 stores instead of four 12-byte ones
 // (the texture-address path, 87 % busy on this variant, charges a dwordx3 like a dwordx4).
+// ---- blend without byte -> float converts (round 3) -------------------------------------------------------------------
+// A byte zero-extended to 16 bits IS the float16 denormal b * 2^-24, and v_fma_mix_f32 takes a float16 operand from either
+// half of a VGPR (denormals honoured: tools/energy_probe.hip's check).  With the four tap weights carrying the 2^24
+// (MIX_S) the products are the same real numbers as cvt(b) * w, the fused multiply-adds round the same sums in the same
+// order: results are bit-identical to the convert + v_pk_fma_f32 form, for 16 instead of 18 VALU instructions per pixel
+// and 18 instead of 22 nJ (one v_perm per tap puts R and G into the halves of a dword; B sits in the upper half of the
+// RGBX texel itself, whose X byte the staging code therefore leaves zero).
+constexpr float MIX_S = 16777216.0f;                  // 2^24
+#ifdef RWH_ABL_NOMIX   // tools/ A/B hook (never defined in the product build): the convert + v_pk_fma_f32 blend of rounds 1-2
+constexpr bool MIX_RGB = false;
+#else
+constexpr bool MIX_RGB = true;
+#endif
+__device__ __forceinline__ float fmix_lo(uint32_t h, float w, float acc) {
+    float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "v"(acc)); return d;
+}
+__device__ __forceinline__ float fmix_hi(uint32_t h, float w, float acc) {
+    float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "v"(acc)); return d;
+}
+__device__ __forceinline__ float fmix_lo_c(uint32_t h, float w, float acc_uniform) {     // first term: accumulator = a constant
+    float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "s"(acc_uniform)); return d;
+}
+__device__ __forceinline__ float fmix_hi_c(uint32_t h, float w, float acc_uniform) {
+    float d; asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(d) : "v"(h), "v"(w), "s"(acc_uniform)); return d;
+}
+// RGBX texel (X == 0) -> R | G << 16
+__device__ __forceinline__ uint32_t rg_halves(uint32_t t) { return __builtin_amdgcn_perm(0u, t, 0x0C010C00u); }
+
 template <bool U8, int CH = 3, bool FOLDED = false>
 __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                        const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
@@ -163,6 +191,18 @@ __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32
             W01 = __builtin_elementwise_fma(WX1, WX0, -W11);
             W10 = __builtin_elementwise_fma(WY1, f2{4294967296.0f, 4294967296.0f}, -W11);
             W00 = __builtin_elementwise_fma(-WX1, WX0, WY0) - W10;
+            if constexpr (CH == 3 && MIX_RGB) {         // the weights carry MIX_S (the callers' constants): taps enter as float16 halves
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int p = j + q;
+                    const float w00 = q ? W00.y : W00.x, w01 = q ? W01.y : W01.x, w10 = q ? W10.y : W10.x, w11 = q ? W11.y : W11.x;
+                    const uint32_t g00 = rg_halves(a0[p]), g01 = rg_halves(b0[p]), g10 = rg_halves(a1[p]), g11 = rg_halves(b1[p]);
+                    o[p][0] = fmix_lo(g11, w11, fmix_lo(g10, w10, fmix_lo(g01, w01, fmix_lo_c(g00, w00, BIAS))));
+                    o[p][1] = fmix_hi(g11, w11, fmix_hi(g10, w10, fmix_hi(g01, w01, fmix_hi_c(g00, w00, BIAS))));
+                    o[p][2] = fmix_hi(b1[p], w11, fmix_hi(a1[p], w10, fmix_hi(b0[p], w01, fmix_hi_c(a0[p], w00, BIAS))));
+                }
+                continue;
+            }
         } else {
             W00 = WX0 * WY0; W01 = WX1 * WY0; W10 = WX0 * WY1; W11 = WX1 * WY1;
         }
@@ -612,6 +652,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     // float32 output: 3 KB more per wave, through which a run's pixels are re-dealt into coalesced 16-byte stores (blend_store)
     constexpr int XPOSE = sizeof(DstT) == 1 ? 0 : 3072;
     constexpr int SLAB = F8Window<LOG_PW>::SLAB + XPOSE;
+    // weight constants: RGB taps enter the blend as float16 halves (b * 2^-24), so the weights carry 2^24 (blend4)
+    constexpr bool MX = CH == 3 && MIX_RGB;
+    constexpr float WS = MX ? W_SCALE * MIX_S : W_SCALE, WO = MX ? W_ONE * MIX_S : W_ONE, WC = MX ? MIX_S : 1.0f;
     __shared__ __attribute__((aligned(16))) unsigned char slab[4][SLAB];
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
@@ -816,10 +859,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 uint4 t4;
                 if constexpr (CH == 4) {                      // RGBA texels are slab texels already
                     t4.x = v[p].a; t4.y = v[p].b; t4.z = v[p].c; t4.w = v[p].d;
-                } else {
-                    t4.x = v[p].a;
-                    t4.y = __builtin_amdgcn_alignbyte(v[p].b, v[p].a, 3);
-                    t4.z = __builtin_amdgcn_alignbyte(v[p].c, v[p].b, 2);
+                } else {                                      // RGBX with X = 0 (the blend reads B as the texel's upper half)
+                    t4.x = v[p].a & 0xFFFFFFu;
+                    t4.y = __builtin_amdgcn_perm(v[p].b, v[p].a, 0x0C050403u);
+                    t4.z = __builtin_amdgcn_perm(v[p].c, v[p].b, 0x0C040302u);
                     t4.w = v[p].c >> 8;
                 }
                 *reinterpret_cast<uint4*>(my + (uint32_t)r0 * lpitch + wl) = t4;
@@ -834,7 +877,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
             run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
-                weights2(lx[j], ly[j], W_SCALE, W_ONE, 1.0f, wx0[j], wx1[j], wy0[j], wy1[j]);
+                weights2(lx[j], ly[j], WS, WO, WC, wx0[j], wx1[j], wy0[j], wy1[j]);
                 const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
@@ -922,9 +965,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                     if constexpr (CH == 4) {
                         t4.x = vb[p].a; t4.y = vb[p].b; t4.z = vb[p].c; t4.w = vb[p].d;
                     } else {
-                        t4.x = vb[p].a;
-                        t4.y = __builtin_amdgcn_alignbyte(vb[p].b, vb[p].a, 3);
-                        t4.z = __builtin_amdgcn_alignbyte(vb[p].c, vb[p].b, 2);
+                        t4.x = vb[p].a & 0xFFFFFFu;
+                        t4.y = __builtin_amdgcn_perm(vb[p].b, vb[p].a, 0x0C050403u);
+                        t4.z = __builtin_amdgcn_perm(vb[p].c, vb[p].b, 0x0C040302u);
                         t4.w = vb[p].c >> 8;
                     }
                     *reinterpret_cast<uint4*>(my + (uint32_t)min(p * Win::RPP, wnrows - Win::RPP) * (uint32_t)Win::LPITCH + wl) = t4;
@@ -942,7 +985,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
                 const bool valid = pixel_valid(j);
-                weights2(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, valid ? 1.0f : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
+                weights2(lx[j], ly[j], valid ? WS : 0.f, valid ? WO : 0.f, valid ? WC : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
                 vbits |= (unsigned)valid << j;
                 // window-relative texel, kept inside the window whatever the coordinate is: a pixel outside the source has
                 // zero weights, and a valid one lies in the window by convexity (up to a floor() that rounding moved across
@@ -969,7 +1012,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         for (int j = 0; j < FP_PX; ++j) {
             const bool valid = pixel_valid(j);
             const int ix = (int)(hx[j] - MAGIC_HI), iy = (int)(hy[j] - MAGIC_HI);
-            weights2(lx[j], ly[j], valid ? W_SCALE : 0.f, valid ? W_ONE : 0.f, valid ? 1.0f : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
+            weights2(lx[j], ly[j], valid ? WS : 0.f, valid ? WO : 0.f, valid ? WC : 0.f, wx0[j], wx1[j], wy0[j], wy1[j]);
             off[j] = valid ? (uint32_t)iy * pitch + (uint32_t)ix * (uint32_t)CH : 0u;
             near_end |= valid & (iy > a.src_h - 3);
             vbits |= (unsigned)valid << j;
@@ -983,9 +1026,9 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 const pk2 r0 = ld8(simg + off[j]);
                 const pk2 r1 = ld8(simg + off[j] + pitch);
                 if constexpr (CH == 4) { a0[j] = r0.a; b0[j] = r0.b; a1[j] = r1.a; b1[j] = r1.b; }
-                else {
-                    a0[j] = r0.a; b0[j] = __builtin_amdgcn_alignbyte(r0.b, r0.a, 3);
-                    a1[j] = r1.a; b1[j] = __builtin_amdgcn_alignbyte(r1.b, r1.a, 3);
+                else {                                        // 24-bit texels, upper byte 0 (see blend4)
+                    a0[j] = r0.a & 0xFFFFFFu; b0[j] = __builtin_amdgcn_perm(r0.b, r0.a, 0x0C050403u);
+                    a1[j] = r1.a & 0xFFFFFFu; b1[j] = __builtin_amdgcn_perm(r1.b, r1.a, 0x0C050403u);
                 }
             }
         } else {  // byte-exact loads, +1 taps clamped to the image (their weight is 0 when clamped)

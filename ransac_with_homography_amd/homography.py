@@ -96,22 +96,13 @@ def calc_correspLinearCollective(u, v):
 
 # ------------------------------------------------------------------------------------- solvers ----
 def calcHomography(u, v, collective=False):
-    """DLT homography, float32 3x3 with h33 == 1 (homography.py:71-88).
-
-    4 float32 pairs (the RANSAC sampling case) run through the batched GPU
-    generator K1 with a single hypothesis.  The N-point form and float64 inputs
-    (never used by the reference's live code) take the host SVD, which is the
-    reference's own arithmetic."""
+    """DLT homography, float32 3x3 with h33 == 1 (homography.py:71-88): the reference's own arithmetic on the host --
+    float32 DLT matrix -> numpy.linalg.svd -> last right-singular vector / its 9th element.  One 8 x 9 SVD costs less than
+    the upload + launch + download a GPU solve of a single sample would, and it IS the reference's solver: samples with
+    a repeated index return LAPACK's null vector like the reference does.  (The batched GPU generator K1 serves
+    `RANSAC.run`'s thousands of samples per call, with this solver as its arbiter: ransac._settle_on_host.)"""
     u = np.asarray(u)
     v = np.asarray(v)
-    if not collective and u.dtype == np.float32 and v.dtype == np.float32 and u.shape[0] == 4:
-        import torch
-        dev = _lib.require_gpu()
-        pa = torch.from_numpy(np.ascontiguousarray(u[:, :2])).to(dev)
-        pb = torch.from_numpy(np.ascontiguousarray(v[:, :2])).to(dev)
-        idx = torch.arange(4, dtype=torch.int32, device=dev).reshape(1, 4)
-        H, _ = kernels.dlt4_batched(pa, pb, idx)
-        return H.cpu().numpy().reshape(3, 3)
     mat = calc_correspCollective(u, v) if collective else calc_corresp(u, v)
     _, _, vt = np.linalg.svd(mat)
     h = vt[-1].reshape(3, 3)

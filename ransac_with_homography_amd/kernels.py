@@ -269,3 +269,21 @@ def decode_best(best_words, k_total):
 def need_count(m, d, n):
     """ransac.py:169,186: count >= m*d/100 + n, as an integer threshold."""
     return int(math.ceil(m * d / 100 + n))
+
+
+class ClockProbe:
+    """Shader clock held while other kernels run (rwh_lab_clock_probe): one wavefront on a side stream that stays resident
+    for `ms` milliseconds of the 100 MHz constant clock and counts shader cycles meanwhile.
+        p = ClockProbe(ms); ... enqueue the kernels being measured ...; mhz = p.mhz()"""
+
+    def __init__(self, ms):
+        lib = _lib.load()
+        self.out = torch.zeros(2, dtype=torch.int64, device=_lib.require_gpu())
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())        # the zero fill above
+        check(lib.rwh_lab_clock_probe(_ptr(self.out), float(ms), ctypes.c_void_p(self.stream.cuda_stream)), "rwh_lab_clock_probe")
+
+    def mhz(self):
+        self.stream.synchronize()
+        cyc, ticks = (int(v) for v in self.out.cpu())
+        return 100.0 * cyc / ticks if ticks else float("nan")

@@ -32,16 +32,33 @@ about 40 SVDs (0.5 ms of host time) for k = 1000.
 There is no CPU implementation of the loop here: without librwh_hip.so and a GPU
 `RANSAC.run` raises `RwhUnavailable`.
 """
+import ctypes
+import os
+
 import numpy as np
 
-from . import _lib, kernels
+from . import _lapack, _lib, kernels
 from .homography import (_pair_rows, calcHomography, calcHomographyLinear, cylindericlMap,  # noqa: F401
                          stitchPanorama)
 
-# An unflagged K1 hypothesis may differ from LAPACK's by float32 round-off on ill-conditioned samples; measured
-# effect on the inlier count: <= 2 on 6 of ~19 300 golden hypotheses (tests/test_gpu_parity.py).  Hypotheses whose
-# count is within this margin of a decision (the best count, the early-exit count) are re-derived on the host.
+# Which hypotheses need the reference's own solver (`_settle_on_host`):
+#   * every sample K1 flags: a repeated index (LAPACK's null vector of the rank-deficient system is arbitrary -- and it is what
+#     the reference uses), a non-finite result, an ill-conditioned sample (RWH_HYP_ILLCOND: collinear triples, equal
+#     coordinates at different indices, |h33| tiny; K1's elimination and LAPACK then round to different float32 H);
+#   * second line: every unflagged hypothesis whose count is within a margin of a decision (the best count, the early-exit
+#     count).  An unflagged K1 H differs from LAPACK's by float32 round-off on 1.8 % of natural samples, which moves its
+#     inlier count by <= 2 on all ~130 000 golden hypotheses and by <= 8 on the lattice / cluster stress sets of
+#     tests/golden/g12_illcond.npz (measured with a float64 emulation of K1, tools/README).  The margin shrinks with the
+#     best count (a count of 17 cannot move by 8): `_margin(best)`.
 RESCORE_MARGIN = 8
+
+
+def _margin(best, cap):
+    """Margin around a decision count `best`: min(cap, 3 + best // 16), nondecreasing in `best` and growing by at most
+    1 per 16 counts, so `best - _margin(best)` is nondecreasing too (a hypothesis inside the margin of a larger best is
+    inside the margin of every smaller one: what lets each shard settle on its own, sharded.gpu_score_slice)."""
+    return min(int(cap), 3 + int(best) // 16)
+
 
 LVL = 0
 
@@ -66,12 +83,29 @@ def _points_rows(P):
     return np.ascontiguousarray(P.T[:, :2], dtype=np.float32)
 
 
-def svd_hypotheses(pts_a, pts_b, idx_rows):
+HOST_THREADS = max(1, min(16, (os.cpu_count() or 1)))
+
+
+def svd_hypotheses(pts_a, pts_b, idx_rows, threads=None):
     """The reference's 4-point solve (homography.py:4-14, 71-88) for n samples at once on the host:
-    float32 DLT matrices -> numpy.linalg.svd (LAPACK dgesdd, float64 inside, cast back to float32) ->
-    last right-singular vector / its 9th element.  The stacked call runs the same LAPACK routine per
-    matrix as n single calls (bit-identical, tests/test_oracle_golden.py).  -> float32 [n, 9]."""
-    idx_rows = np.asarray(idx_rows).reshape(-1, 4)
+    float32 DLT matrices -> LAPACK dgesdd (float64 inside, cast back to float32) -> last right-singular vector / its
+    9th element.  -> float32 [n, 9].
+
+    Native form: `rwh_host_dlt4_svd` runs the loop in librwh_hip.so's host code on `threads` cores, calling -- by address
+    -- the very dgesdd numpy.linalg.svd calls (`_lapack.dgesdd_address`): the same numbers bit for bit
+    (tests/test_settle_cpu.py), ~6 us per sample per core instead of ~11 us under the interpreter lock.  If that symbol
+    cannot be found (another numpy build) or the library is missing, the stacked numpy call below does the same work."""
+    idx_rows = np.ascontiguousarray(np.asarray(idx_rows).reshape(-1, 4), dtype=np.int32)
+    n = idx_rows.shape[0]
+    addr = _lapack.dgesdd_address()
+    if addr is not None and n and os.path.exists(_lib.LIB_PATH):
+        pa = np.ascontiguousarray(pts_a, dtype=np.float32)
+        pb = np.ascontiguousarray(pts_b, dtype=np.float32)
+        out = np.empty((n, 9), dtype=np.float32)
+        st = _lib.load().rwh_host_dlt4_svd(pa.ctypes.data, pb.ctypes.data, pa.shape[0], idx_rows.ctypes.data, n,
+                                           ctypes.c_void_p(addr), int(threads or HOST_THREADS), out.ctypes.data)
+        if st == 0:
+            return out
     flat = idx_rows.reshape(-1)
     mats = _pair_rows(pts_a[flat], pts_b[flat], -1).reshape(-1, 8, 9)
     with np.errstate(all="ignore"):          # h[8] == 0 divides like the reference does (inf / nan rows score 0)
@@ -80,59 +114,106 @@ def svd_hypotheses(pts_a, pts_b, idx_rows):
         return np.ascontiguousarray(h / h[:, 8:9])
 
 
-def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, method, margin, stats=None):
+def repeated_rows(idx):
+    """Samples of a K x >=4 index table whose first four indices are not distinct (what K1 flags RWH_HYP_REPEATED):
+    known to the host before anything is launched."""
+    a, b, c, d = (np.asarray(idx)[:, i] for i in range(4))
+    return (a == b) | (a == c) | (a == d) | (b == c) | (b == d) | (c == d)
+
+
+class _Settled(object):
+    """Hypotheses re-derived with the reference's solver so far: index -> (H row, count, where its mask lives)."""
+
+    def __init__(self, k):
+        self.done = np.zeros(k, dtype=bool)
+        self.batches = []          # (indices, H float32 [n, 9], mask tensor [n, words] on the device)
+        self.where = {}
+
+    def add(self, cand, H, masks):
+        b = len(self.batches)
+        self.batches.append((cand, H, masks))
+        self.done[cand] = True
+        for j, i in enumerate(cand.tolist()):
+            self.where[i] = (b, j)
+
+    def mask_words(self, i):
+        if i not in self.where:
+            return None
+        b, j = self.where[i]
+        return self.batches[b][2][j].cpu().numpy()
+
+    def rows(self):
+        return {i: self.batches[b][1][j] for i, (b, j) in self.where.items()}
+
+
+def presettle(pa_dev, pb_dev, pa, pb, idx_host, rows, th, method):
+    """First part of the settle step, for samples the HOST can name before the GPU has said anything (repeated indices):
+    their reference H by `svd_hypotheses` -- host time that overlaps the search already enqueued on the GPU -- then K2 on
+    those rows, enqueued behind the search.  Returns (rows, H, counts tensor, masks tensor) for `_settle_on_host(pre=...)`."""
+    import torch
+    rows = np.asarray(rows, dtype=np.int64)
+    if rows.size == 0:
+        return None
+    H = svd_hypotheses(pa, pb, idx_host[rows][:, :4])
+    hd = torch.from_numpy(H).to(pa_dev.device)
+    cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.new_best(pa_dev.device))
+    return rows, H, cnt, msk
+
+
+def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, method, margin, stats=None, pre=None):
     """Accept rules of ransac.py:186-202 over K1/K2's results, exact with respect to the reference's solver.
 
-    counts / flags: host copies of K2's counts and K1's flags for the k hypotheses of `idx_host`.  Hypotheses are
-    "settled" (H from the host SVD, count + mask from K2 on that H) in rounds until every hypothesis that can take
-    part in the decision is settled:
-      * nothing after the first hypothesis that certainly reaches `need` (count >= need + margin) is ever looked at
-        by the reference (`break`, ransac.py:186-190);
-      * inside that prefix: every flagged hypothesis (its reference H is LAPACK's arbitrary null vector), every one
-        within `margin` of `need`, and every one within `margin` of the running maximum.
-    Returns (winner | None, early, count, mask_words | None, H_rows, counts): mask_words is the winner's uint64 mask
-    if the winner was settled here (None: take K2's own mask for it), H_rows maps settled index -> float32[9], counts
-    is the int64 count table with the settled entries replaced."""
+    counts / flags: host copies of K2's counts and K1's flags for the k hypotheses of `idx_host`; `pre`: what `presettle`
+    returned (its counts are read here).  Hypotheses are "settled" (H from the host SVD, count + mask from K2 on that H)
+    in rounds until every hypothesis that can take part in the decision is settled:
+      * nothing after the first hypothesis that certainly reaches `need` (settled: count >= need; unflagged: count >= need
+        + margin) is ever looked at by the reference (`break`, ransac.py:186-190);
+      * inside that prefix: every flagged hypothesis (repeated index, non-finite, ill-conditioned: K1's H says nothing
+        about the reference's), every unflagged one within `_margin` of `need` or of the best trustworthy count.
+    Usually ONE round beyond `pre`.  Returns (winner | None, early, count, mask_words | None, H_rows, counts): mask_words
+    is the winner's uint64 mask if the winner was settled here (None: take K2's own mask for it), H_rows maps settled
+    index -> float32[9], counts is the int64 count table with the settled entries replaced."""
     import torch
     k = counts.shape[0]
     counts = counts.astype(np.int64)
-    settled = np.zeros(k, dtype=bool)
+    st = _Settled(k)
     suspect = flags != 0
-    masks = {}
-    rows = {}
     n_rounds = 0
+    if pre is not None:
+        rows, H, cnt, msk = pre
+        counts[rows] = cnt.cpu().numpy()
+        st.add(rows, H, msk)
     while True:
-        # the reference never runs past the first hypothesis that reaches `need` (certainly: settled, or by a margin)
-        hit = np.flatnonzero(np.where(settled, counts >= need, counts >= need + margin))
+        settled = st.done
+        trusted = settled | ~suspect                      # counts that mean something: the reference's, or K1's within a margin
+        sure = np.where(settled, counts >= need, ~suspect & (counts >= need + _margin(need, margin)))
+        hit = np.flatnonzero(sure)
         end = int(hit[0]) + 1 if hit.size else k
         c = counts[:end]
-        best = int(c.max()) if end else 0
-        cand = np.flatnonzero(~settled[:end] & suspect[:end])
-        if cand.size == 0:   # flagged samples first: their true counts can move the best the margin is measured from
-            cand = np.flatnonzero(~settled[:end] & ((c >= best - margin) | (c >= need - margin)))
+        tc = c[trusted[:end]]
+        best = int(tc.max()) if tc.size else 0
+        open_ = ~settled[:end]
+        cand = np.flatnonzero(open_ & (suspect[:end] | (c >= best - _margin(best, margin)) | (c >= need - _margin(need, margin))))
         if cand.size == 0:
             break
         n_rounds += 1
-        H = svd_hypotheses(pa, pb, idx_host[cand])
+        H = svd_hypotheses(pa, pb, idx_host[cand][:, :4])
         hd = torch.from_numpy(H).to(pa_dev.device)
         cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.new_best(pa_dev.device))
-        msk = msk.cpu().numpy()
         counts[cand] = cnt.cpu().numpy()
-        settled[cand] = True
-        for j, i in enumerate(cand.tolist()):
-            masks[i] = msk[j]
-            rows[i] = H[j]
+        st.add(cand, H, msk)
     if stats is not None:
-        stats["host_settled"] = int(settled.sum())
+        stats["host_settled"] = int(st.done.sum())
         stats["host_rounds"] = n_rounds
+        stats["flagged"] = int(suspect.sum())
     hit = np.flatnonzero(c >= need)
     if hit.size:
         w, early = int(hit[0]), True
     elif end and c.max() > 0:
         w, early = int(np.argmax(c)), False               # first index of the maximum (ransac.py:199: strict >)
     else:
-        return None, False, 0, None, rows, counts
-    return w, early, int(c[w]), masks.get(w), rows, counts
+        return None, False, 0, None, st.rows(), counts
+    return w, early, int(c[w]), st.mask_words(w), st.rows(), counts
 
 
 class Model(object):
@@ -267,30 +348,35 @@ class RANSAC(object):
         assert mx == my, "data observation not consistent!"
         if method not in _lib.RWH_LOSS:
             exit("Invalid method!")
-        if self.n != 4:
-            raise NotImplementedError("the homography model samples exactly 4 correspondences (ransac.py:270)")
+        if self.n < 4:
+            # ransac.py:180 -> homography.py:9: calc_corresp reads u[3] of an n-point sample
+            raise IndexError("index 3 is out of bounds for axis 0 with size %d" % self.n)
         dev = _lib.require_gpu()
         need = mx * self.d / 100 + self.n
         k = int(self.k)
 
-        # sampling: identical stream to k successive randint(0, mx, 4) calls (ransac.py:177)
+        # sampling: identical stream to k successive randint(0, mx, n) calls (ransac.py:177); the model is fitted on the
+        # first four of the n sampled correspondences (ransac.py:180 -> homography.py:4-14)
         rng_state = np.random.get_state()
         idx_host = np.random.randint(0, mx, (k, self.n))
 
         pa_host, pb_host = _points_rows(X), _points_rows(Y)
         pa = torch.from_numpy(pa_host).to(dev)
         pb = torch.from_numpy(pb_host).to(dev)
-        idx = torch.from_numpy(idx_host.astype(np.int32)).to(dev)
+        idx = torch.from_numpy(np.ascontiguousarray(idx_host[:, :4], dtype=np.int32)).to(dev)
         ws = kernels.SearchWorkspace(k, mx, dev)
         need_i = kernels.need_count(mx, self.d, self.n)
         th = _weak_threshold(self.th)
-        kernels.ransac_search(pa, pb, idx, th, method, need_i, ws)
+        kernels.ransac_search(pa, pb, idx, th, method, need_i, ws)             # enqueued; the host goes on
+        # while the GPU searches: the reference's solver for the samples the host already knows K1 will flag
+        pre = presettle(pa, pb, pa_host, pb_host, idx_host, np.flatnonzero(repeated_rows(idx_host)), th, method)
         Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
-        counts_host = counts.cpu().numpy()
-        stats = {}
+        both = torch.cat([counts, flags.to(torch.int32)]).cpu().numpy()        # one readback for counts + flags
+        counts_host, flags_host = both[:k], both[k:].astype(np.uint8)
+        stats = {"raw_counts": counts_host.copy()}           # K2 on K1's own H, before the settle step
         winner, early, totalfit, mask_words, settled_rows, counts_host = _settle_on_host(
-            pa, pb, pa_host, pb_host, idx_host, counts_host, flags.cpu().numpy(), need_i, th, method,
-            self.rescore_margin, stats)
+            pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need_i, th, method,
+            self.rescore_margin, stats, pre=pre)
 
         if early:  # leave the generator where the reference's `break` would
             np.random.set_state(rng_state)
@@ -357,8 +443,8 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     import torch
     if method not in _lib.RWH_LOSS:
         exit("Invalid method!")
-    if n != 4:
-        raise NotImplementedError("the homography model samples exactly 4 correspondences (ransac.py:270)")
+    if n < 4:
+        raise IndexError("index 3 is out of bounds for axis 0 with size %d" % n)   # as RANSAC.run (homography.py:9)
     dev = _lib.require_gpu()
     P = len(datas)
     if P == 0:
@@ -380,7 +466,7 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     needs = torch.tensor(needs_host, dtype=torch.int32, device=dev)
     ws = kernels.BatchWorkspace(P, int(k), max(max(sizes), 1), dev)
     if idx is not None:
-        table = torch.from_numpy(np.stack([np.asarray(t).astype(np.int32) for t in idx])).to(dev)
+        table = torch.from_numpy(np.stack([np.asarray(t)[:, :4].astype(np.int32) for t in idx])).to(dev)   # fit on the first four
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, idx=table)
     else:
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed,
@@ -396,7 +482,7 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
         winners, win_counts, host_masks = [], [], []
         for p in range(P):
             o0, o1 = int(offsets[p]), int(offsets[p + 1])
-            w, early, cnt, words, _, _ = _settle_on_host(pa[o0:o1], pb[o0:o1], pa_host[o0:o1], pb_host[o0:o1], np.asarray(idx[p]),
+            w, early, cnt, words, _, _ = _settle_on_host(pa[o0:o1], pb[o0:o1], pa_host[o0:o1], pb_host[o0:o1], np.asarray(idx[p])[:, :4],
                                                      counts_host[p], flags_host[p], needs_host[p], _weak_threshold(th),
                                                      method, RESCORE_MARGIN)
             winners.append((w, None, early)); win_counts.append(cnt); host_masks.append(words)

@@ -26,7 +26,7 @@ def test_exports_match_header(lib):
     assert declared == set(_lib.EXPORTS)
     for name in declared:
         assert getattr(lib, name) is not None
-    assert lib.rwh_abi_version() == 1
+    assert lib.rwh_abi_version() == _lib.ABI_VERSION == int(re.search(r"#define RWH_ABI_VERSION (\d+)", hdr).group(1))
     assert lib.rwh_strerror(-1) == b"invalid argument"
 
 

@@ -161,3 +161,33 @@ def test_g8_stitch():
     z = load_golden("g11_stitch_gradient")      # the alpha ramp of homography.py:259-266
     check_digest(z, "stitch_gradient", orc.stitch_panorama(B.copy(), A.copy(), load_golden("g8_stitch")["H_notebook"], blending="Gradient"))
     check_digest(z, "stitch_g5_gradient", orc.stitch_panorama(B.copy(), A.copy(), load_golden("g8_stitch")["H_g5"], blending="Gradient"))
+
+
+def test_oracle_ransac_illcond_config4x8_and_n6(matches):
+    """Round-3 fixtures, written by the unmodified reference: g12 (lattice / cluster problems: ill-conditioned samples without
+    a repeated index), g13 (BASELINE config 4's RANSAC at the x8 scale; HomoModel(n = 6): six indices per iteration, fit on
+    the first four, exit at d + 6) -- the oracle reproduces winner, count, inlier list and the generator's position."""
+    z = load_golden("g12_illcond")
+    for key in [str(c) for c in z["cases"]]:
+        tag, s, th, d, k, m = key.split("_")
+        A, B = z["ptsA_" + tag], z["ptsB_" + tag]
+        np.random.seed(int(s[1:]))
+        with np.errstate(all="ignore"):
+            H, inl, cnt, it = orc.ransac_run(A.T, B.T, th=int(th[2:]), d=int(d[1:]), n=4, k=int(k[1:]), method=m)
+        assert int(cnt) == int(z[key + "_count"]) and it == int(z[key + "_winner"]), key
+        assert np.array_equal(inl[0], z[key + "_inliers"]), key
+        assert np.allclose(H, z[key + "_H"], rtol=0, atol=0), key
+    ptsA, ptsB = matches
+    g = load_golden("g13_config4_x8")
+    np.random.seed(0)
+    H, inl, cnt, it = orc.ransac_run((ptsA * 8).T, (ptsB * 8).T, th=32, d=95, n=4, k=1500, method="fwd")
+    assert int(cnt) == int(g["count"]) == 114 and it == int(g["winner"]) and np.array_equal(inl[0], g["inliers"])
+    assert np.array_equal(H, g["H"])
+    for seed, d in ((0, 70), (3, 50)):
+        key = "n6_s%d_d%d" % (seed, d)
+        np.random.seed(seed)
+        H, inl, cnt, it = orc.ransac_run(ptsA.T, ptsB.T, th=5, d=d, n=6, k=1000, method="fwd")
+        assert int(cnt) == int(g[key + "_count"]) and np.array_equal(inl[0], g[key + "_inliers"]) and np.array_equal(H, g[key + "_H"])
+        assert np.random.randint(0, 1 << 30) == int(g[key + "_next_draw"])
+    with pytest.raises(IndexError):
+        orc.calc_homography(ptsA[:3], ptsB[:3])

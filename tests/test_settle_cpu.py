@@ -101,3 +101,69 @@ def test_settle_without_suspects_keeps_device_decision(matches, oracle_scorer):
     assert (lo + w, cnt, early) == (int(g["winner"]), int(g["winner_count"]), False)
     bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:185]
     assert np.array_equal(np.nonzero(bits)[0], g["winner_inliers"])
+
+
+def test_native_host_solver_is_numpy_svd(matches):
+    """rwh_host_dlt4_svd (the settle step's native loop over numpy's own dgesdd) == the stacked numpy.linalg.svd path ==
+    the reference's per-sample H (G2: 10 000 samples, 373 with a repeated index), bit for bit; 1 and many threads."""
+    from ransac_with_homography_amd import _lapack
+    from ransac_with_homography_amd.homography import _pair_rows
+    ptsA, ptsB = matches
+    g = load_golden("g2_hyp_seed0")
+    if _lapack.dgesdd_address() is None:
+        pytest.skip("numpy's LAPACK symbol not found: svd_hypotheses stays on numpy.linalg.svd")
+    for threads in (1, 5):
+        got = impl.svd_hypotheses(ptsA, ptsB, g["idx"], threads=threads)
+        assert np.array_equal(got.view(np.uint32), g["H"].view(np.uint32))
+    flat = g["idx"][:3000].reshape(-1)
+    mats = _pair_rows(ptsA[flat], ptsB[flat], -1).reshape(-1, 8, 9)
+    with np.errstate(all="ignore"):
+        _, _, vt = np.linalg.svd(mats)
+        ref = vt[:, -1, :] / vt[:, -1, 8:9]
+    assert np.array_equal(impl.svd_hypotheses(ptsA, ptsB, g["idx"][:3000]).view(np.uint32), ref.astype(np.float32).view(np.uint32))
+    # the single-call solver of the module surface takes the same host path (homography.py:71-88), degenerate samples included
+    from ransac_with_homography_amd import homography as hg
+    for i in list(np.flatnonzero(g["degenerate"])[:20]) + list(range(20)):
+        H = hg.calcHomography(ptsA[g["idx"][i]], ptsB[g["idx"][i]])
+        assert H.dtype == np.float32 and np.array_equal(H.reshape(9).view(np.uint32), g["H"][i].view(np.uint32))
+
+
+def test_illcond_flag_and_settle_on_lattice_problems(oracle_scorer):
+    """Ill-conditioned samples WITHOUT a repeated index (three collinear source points, equal coordinates at different
+    indices): K1's elimination returns a finite H that has nothing to do with LAPACK's (counts apart by hundreds).  With
+    K1 emulated in float64 (tests/k1_emulation.py: same elimination, same flag thresholds) and the oracle as scorer, the
+    settle step must return the reference's winner, count and inlier list on every case of g12 (written by the unmodified
+    reference): lattice and cluster problems, with and without an early exit, ties at the top."""
+    from k1_emulation import RWH_HYP_ILLCOND, RWH_HYP_REPEATED, dlt4
+    z = load_golden("g12_illcond")
+    for key in [str(c) for c in z["cases"]]:
+        tag, s, th, d, k, m = key.split("_")
+        A, B = z["ptsA_" + tag], z["ptsB_" + tag]
+        idx = z[key + "_idx"]
+        ref_counts = z[key + "_hyp_counts"].astype(np.int64)
+        th_f = float(th[2:])
+        H, flags = dlt4(A, B, idx)
+        # what the GPU would report: K2 on K1's H (NaN rows count 0)
+        dev_counts = np.zeros(len(idx), np.int32)
+        X, Y = A.T, B.T
+        with np.errstate(all="ignore"):
+            for i in range(len(idx)):
+                if np.isfinite(H[i]).all():
+                    dev_counts[i] = int((orc.compute_loss(H[i].reshape(3, 3), X, Y, m) < th_f).sum())
+        unflagged = flags == 0
+        dif = np.abs(dev_counts.astype(np.int64) - ref_counts)
+        assert dif[unflagged].max() <= impl.RESCORE_MARGIN, (key, dif[unflagged].max())      # the flag leaves only small differences
+        assert dif[(flags & RWH_HYP_ILLCOND) != 0].max() > 20, key                            # ... and catches the big ones
+        assert ((flags & RWH_HYP_REPEATED) != 0).sum() == sum(len(set(r)) < 4 for r in idx.tolist())
+        need = kernels.need_count(A.shape[0], int(d[1:]), 4)
+        stats = {}
+        pre = impl.presettle(torch.from_numpy(A), torch.from_numpy(B), A, B, idx, np.flatnonzero(impl.repeated_rows(idx)), th_f, m)
+        w, early, cnt, words, rows, counts = impl._settle_on_host(torch.from_numpy(A), torch.from_numpy(B), A, B, idx, dev_counts, flags,
+                                                                  need, th_f, m, impl.RESCORE_MARGIN, stats, pre=pre)
+        assert w == int(z[key + "_winner"]) and cnt == int(z[key + "_count"]) and early == bool(z[key + "_early"]), (key, w, cnt, early)
+        if words is None:           # the winner was not settled: its mask is K2's own on K1's H
+            inl = np.flatnonzero(orc.compute_loss(H[w].reshape(3, 3), X, Y, m) < th_f)
+        else:
+            inl = np.flatnonzero(np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:A.shape[0]])
+        assert np.array_equal(inl, z[key + "_inliers"]), key
+        assert stats["host_rounds"] <= 2, (key, stats)

@@ -1,0 +1,262 @@
+// Developer microbenchmark (NOT part of the product): issue cost, held clock and board power of single instruction kinds
+// on MI355X -- the chip is power-limited under the warp kernel (it holds ~1.87 GHz instead of 2.4), so the quantity to
+// minimise is energy per pixel.  Every CU runs 8 waves per SIMD of one loop body for ~2.5 s; rocm-smi is sampled meanwhile.
+//   hipcc -O3 --offload-arch=gfx950 tools/energy_probe.hip -o tools/energy_probe -lpthread && gpurun -- ./tools/energy_probe [filter]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <atomic>
+#include <string>
+#include <vector>
+#include <algorithm>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
+constexpr int ITERS = 2048;
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4 __attribute__((ext_vector_type(4)));
+typedef unsigned u3 __attribute__((ext_vector_type(3)));
+typedef unsigned u2 __attribute__((ext_vector_type(2)));
+
+#define STAMP0 const unsigned long long c0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#define STAMP1 if (threadIdx.x == 0 && blockIdx.x < 2048) { stamps[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0; stamps[2 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime() - r0; }
+#define ARGS unsigned long long* stamps, float* out, unsigned seed, const unsigned* gsrc, unsigned* gdst
+#define R8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+// per-lane pseudo-random operands so that the datapaths toggle like they do on image data
+#define RND(k) ((seed + threadIdx.x * 2654435761u + (k) * 40503u) * 2246822519u)
+#define DECL_F float a0=(float)(RND(0)>>8),a1=(float)(RND(1)>>8),a2=(float)(RND(2)>>8),a3=(float)(RND(3)>>8),a4=(float)(RND(4)>>8),a5=(float)(RND(5)>>8),a6=(float)(RND(6)>>8),a7=(float)(RND(7)>>8); float b=1.0f+(float)(RND(8)>>8)*1e-9f, c=(float)(RND(9)>>8)*1e-3f; (void)b; (void)c
+#define DECL_U unsigned a0=RND(0),a1=RND(1),a2=RND(2),a3=RND(3),a4=RND(4),a5=RND(5),a6=RND(6),a7=RND(7); unsigned b=RND(8), c=RND(9); (void)b; (void)c
+#define DECL_D double a0=(double)RND(0),a1=(double)RND(1),a2=(double)RND(2),a3=(double)RND(3),a4=(double)RND(4),a5=(double)RND(5),a6=(double)RND(6),a7=(double)RND(7); double b=1.0+(double)RND(8)*1e-19, c=(double)RND(9)*1e-3; (void)b; (void)c
+#define SUMF (a0+a1+a2+a3+a4+a5+a6+a7)
+
+#define VK(NAME, DECL, ASM, CONS, SINK) \
+__global__ __launch_bounds__(256) void NAME(ARGS) { DECL; STAMP0 \
+    for (int it = 0; it < ITERS; ++it) { \
+        asm volatile(ASM : "+v"(a0) : CONS); asm volatile(ASM : "+v"(a1) : CONS); asm volatile(ASM : "+v"(a2) : CONS); asm volatile(ASM : "+v"(a3) : CONS); \
+        asm volatile(ASM : "+v"(a4) : CONS); asm volatile(ASM : "+v"(a5) : CONS); asm volatile(ASM : "+v"(a6) : CONS); asm volatile(ASM : "+v"(a7) : CONS); } \
+    STAMP1 if (seed == 77777u) out[threadIdx.x] = (float)(SINK); }
+
+#define COMMA ,
+VK(k_fma_f32, DECL_F, "v_fma_f32 %0, %0, %1, %2", "v"(b) COMMA "v"(c), SUMF)
+#define COMMA ,
+VK(k_add_f32, DECL_F, "v_add_f32 %0, %0, %1", "v"(c), SUMF)
+VK(k_mul_f32, DECL_F, "v_mul_f32 %0, %0, %1", "v"(b), SUMF)
+VK(k_fmac_f32, DECL_F, "v_fmac_f32 %0, %1, %2", "v"(b) COMMA "v"(c), SUMF)
+VK(k_sub_f32, DECL_F, "v_sub_f32 %0, %0, %1", "v"(c), SUMF)
+VK(k_max_f32, DECL_F, "v_max_f32 %0, %0, %1", "v"(c), SUMF)
+VK(k_mov_b32, DECL_U, "v_mov_b32 %0, %1", "v"(b), SUMF)
+VK(k_add_u32, DECL_U, "v_add_u32 %0, %0, %1", "v"(b), SUMF)
+VK(k_and_b32, DECL_U, "v_and_b32 %0, %0, %1", "v"(b), SUMF)
+VK(k_lshl_b32, DECL_U, "v_lshlrev_b32 %0, 1, %0", "v"(b), SUMF)
+VK(k_lshl_add, DECL_U, "v_lshl_add_u32 %0, %0, 2, %1", "v"(b), SUMF)
+VK(k_mad_u24, DECL_U, "v_mad_u32_u24 %0, %0, %1, %2", "v"(b) COMMA "v"(c), SUMF)
+VK(k_mul_u24, DECL_U, "v_mul_u32_u24 %0, %0, %1", "v"(b), SUMF)
+VK(k_perm, DECL_U, "v_perm_b32 %0, %0, %1, %2", "v"(b) COMMA "v"(c), SUMF)
+VK(k_alignbyte, DECL_U, "v_alignbyte_b32 %0, %0, %1, 3", "v"(b), SUMF)
+VK(k_and_or, DECL_U, "v_and_or_b32 %0, %0, %1, %2", "v"(b) COMMA "v"(c), SUMF)
+VK(k_bfe, DECL_U, "v_bfe_u32 %0, %0, 8, 8", "v"(b), SUMF)
+VK(k_cvt_ubyte, DECL_U, "v_cvt_f32_ubyte1 %0, %1", "v"(b), SUMF)
+VK(k_cvt_u32, DECL_U, "v_cvt_f32_u32 %0, %0", "v"(b), SUMF)
+VK(k_cvt_pk_u8, DECL_F, "v_cvt_pk_u8_f32 %0, %1, 1, %0", "v"(c), SUMF)
+VK(k_cvt_pknorm, DECL_F, "v_cvt_pknorm_u16_f32 %0, %1, %0", "v"(c), SUMF)
+VK(k_mul_sdwa, DECL_U, "v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD", "v"(b) COMMA "v"(c), SUMF)
+VK(k_add_sdwa, DECL_U, "v_add_f32_sdwa %0, %1, %0 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD", "v"(b), SUMF)
+VK(k_fma_mix, DECL_F, "v_fma_mix_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,0,0]", "v"(__float_as_uint(c)) COMMA "v"(b), SUMF)
+VK(k_dot2_f16, DECL_F, "v_dot2_f32_f16 %0, %1, %2, %0", "v"(__float_as_uint(c)) COMMA "v"(__float_as_uint(b)), SUMF)
+VK(k_fma_f64, DECL_D, "v_fma_f64 %0, %0, %1, %2", "v"(b) COMMA "v"(c), SUMF)
+VK(k_add_f64, DECL_D, "v_add_f64 %0, %0, %1", "v"(c), SUMF)
+VK(k_mul_f64, DECL_D, "v_mul_f64 %0, %0, %1", "v"(b), SUMF)
+VK(k_rcp_f64, DECL_D, "v_rcp_f64 %0, %0", "v"(b), SUMF)
+VK(k_cndmask, DECL_U, "v_cndmask_b32 %0, %0, %1, vcc", "v"(b), SUMF)
+
+__global__ __launch_bounds__(256) void k_pk_fma(ARGS) {
+    f2 a0 = {(float)(RND(0)>>8), (float)(RND(1)>>8)}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f2 b = {1.0f + (float)(RND(8)>>8) * 1e-9f, 1.0f - (float)(RND(7)>>8) * 1e-9f}, c = {(float)(RND(9)>>8) * 1e-3f, (float)(RND(6)>>8) * 1e-3f};
+    STAMP0
+    for (int it = 0; it < ITERS; ++it) {
+#define X(i) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(a##i) : "v"(b), "v"(c));
+        R8(X)
+#undef X
+    }
+    STAMP1
+    f2 s = a0+a1+a2+a3+a4+a5+a6+a7;
+    if (seed == 77777u) out[threadIdx.x] = s.x + s.y;
+}
+__global__ __launch_bounds__(256) void k_pk_mul(ARGS) {
+    f2 a0 = {(float)(RND(0)>>8), (float)(RND(1)>>8)}, a1 = a0 + 1.f, a2 = a0 + 2.f, a3 = a0 + 3.f, a4 = a0 + 4.f, a5 = a0 + 5.f, a6 = a0 + 6.f, a7 = a0 + 7.f;
+    f2 b = {1.0f + (float)(RND(8)>>8) * 1e-9f, 1.0f - (float)(RND(7)>>8) * 1e-9f};
+    STAMP0
+    for (int it = 0; it < ITERS; ++it) {
+#define X(i) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(a##i) : "v"(b));
+        R8(X)
+#undef X
+    }
+    STAMP1
+    f2 s = a0+a1+a2+a3+a4+a5+a6+a7;
+    if (seed == 77777u) out[threadIdx.x] = s.x + s.y;
+}
+
+// ---- LDS -------------------------------------------------------------------------------------------------------------
+// stride in dwords between neighbouring lanes: 1 = conflict-free b32, 4 = the warp kernel's tap pattern (16 B apart)
+template <int STRIDE, int KIND>   // KIND 0: ds_read_b32, 1: ds_read2_b32 (2 dwords), 2: ds_read_b64, 3: ds_read_b128, 4: ds_write_b32, 5: ds_write_b128
+__global__ __launch_bounds__(256) void k_lds(ARGS) {
+    __shared__ unsigned lds[4][2048];      // 8 KB per wave, 32 KB per block
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int i = lane; i < 2048; i += 64) lds[wave][i] = RND(i);
+    __syncthreads();
+    unsigned acc = 0;
+    const unsigned base = (unsigned)(uintptr_t)&lds[wave][0] + (unsigned)(lane * STRIDE * 4) % 4096u;
+    STAMP0
+    for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned addr = base + (unsigned)r * 16u;
+            if (KIND == 0) { unsigned v; asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(addr)); asm volatile("s_waitcnt lgkmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v)); }
+            if (KIND == 1) { u2 v; asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(v) : "v"(addr)); asm volatile("s_waitcnt lgkmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v.x)); }
+            if (KIND == 2) { u2 v; asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(addr & ~7u)); asm volatile("s_waitcnt lgkmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v.x)); }
+            if (KIND == 3) { u4 v; asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr & ~15u)); asm volatile("s_waitcnt lgkmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v.x)); }
+            if (KIND == 4) { asm volatile("ds_write_b32 %0, %1" : : "v"(addr), "v"(acc)); }
+            if (KIND == 5) { u4 v = {acc, acc + 1, acc + 2, acc + 3}; asm volatile("ds_write_b128 %0, %1" : : "v"(addr & ~15u), "v"(v)); }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)");
+    STAMP1
+    if (seed == 77777u) out[threadIdx.x] = (float)acc;
+}
+
+// ---- global memory: loads that hit in L2 (each block walks its own 16 KB window), 12 or 16 bytes per lane ------------------
+template <int BYTES>
+__global__ __launch_bounds__(256) void k_gload_l2(ARGS) {
+    const unsigned char* p = reinterpret_cast<const unsigned char*>(gsrc) + (size_t)blockIdx.x * 65536 + threadIdx.x * BYTES;
+    unsigned acc = 0;
+    STAMP0
+    for (int it = 0; it < ITERS / 4; ++it) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const unsigned char* q = p + ((it * 8 + r) & 15) * 4096;
+            if (BYTES == 12) { u3 v; asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(v) : "v"(q)); asm volatile("s_waitcnt vmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v.x)); }
+            if (BYTES == 16) { u4 v; asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(q)); asm volatile("s_waitcnt vmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v.x)); }
+            if (BYTES == 4) { unsigned v; asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(q)); asm volatile("s_waitcnt vmcnt(6)\n v_xor_b32 %0, %0, %1" : "+v"(acc) : "v"(v)); }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)");
+    STAMP1
+    if (seed == 77777u) out[threadIdx.x] = (float)acc;
+}
+// streaming read / write of 1 GiB, 16 B per lane (HBM energy per byte)
+__global__ __launch_bounds__(256) void k_stream_read(ARGS) {
+    STAMP0
+    const size_t n4 = (size_t)1 << 26;
+    const uint4* s4 = reinterpret_cast<const uint4*>(gsrc);
+    unsigned acc = 0;
+    for (int rep = 0; rep < 4; ++rep)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) { const uint4 v = s4[i]; acc ^= v.x ^ v.y ^ v.z ^ v.w; }
+    STAMP1
+    if (acc == 0x12345u) out[threadIdx.x] = 1.f;
+}
+__global__ __launch_bounds__(256) void k_stream_write(ARGS) {
+    STAMP0
+    const size_t n4 = (size_t)1 << 26;
+    uint4* d4 = reinterpret_cast<uint4*>(gdst);
+    const uint4 v = {RND(0), RND(1), RND(2), RND(3)};
+    for (int rep = 0; rep < 4; ++rep)
+        for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) d4[i] = v;
+    STAMP1
+}
+__global__ __launch_bounds__(256) void k_idle(ARGS) {   // resident, sleeping waves: the floor
+    STAMP0
+    for (int it = 0; it < ITERS * 2; ++it) __builtin_amdgcn_s_sleep(32);
+    STAMP1
+}
+
+// functional check of the SDWA byte -> float32-denormal multiply and of v_cvt_pknorm_u16_f32
+__global__ void k_check(float* out) {
+    const unsigned tap = 0x00FF8001u;   // bytes 01 80 FF 00
+    const float w = 0.25f * 0x1p126f;
+    float r0, r1, r2;
+    asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r0) : "v"(tap), "v"(w));
+    asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r1) : "v"(tap), "v"(w));
+    asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r2) : "v"(tap), "v"(w));
+    out[0] = r0 * 0x1p23f; out[1] = r1 * 0x1p23f; out[2] = r2 * 0x1p23f;      // expect 0.25, 32, 63.75
+    unsigned pk;
+    const float x = (200.7f * 256.f - 0.5f) / 65535.f, y = (13.0f * 256.f - 0.5f) / 65535.f;
+    asm volatile("v_cvt_pknorm_u16_f32 %0, %1, %2" : "=v"(pk) : "v"(x), "v"(y));
+    out[3] = (float)(pk & 0xFFFFu); out[4] = (float)(pk >> 16);               // expect 51379 (200<<8 | 179), 3327 / 3328
+    float m;
+    const unsigned half = 0x00370012u;  // hi half 0x0037 = 55 as an f16 denormal
+    asm volatile("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(m) : "v"(half), "v"(0x1p24f), "v"(0.5f));
+    out[5] = m;                                                                // expect 55.5
+}
+
+struct Case { const char* name; void (*k)(ARGS); double inst_per_wave; double bytes; };
+static std::atomic<bool> g_stop{false};
+static void sampler(std::vector<double>* watts) {
+    while (!g_stop) {
+        FILE* f = popen("rocm-smi --showpower 2>/dev/null | grep -i 'Power (W)'", "r");
+        if (f) { char buf[512]; if (fgets(buf, sizeof buf, f)) { const char* p = strrchr(buf, ':'); if (p) watts->push_back(atof(p + 1)); } pclose(f); }
+        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+    }
+}
+
+int main(int argc, char** argv) {
+    const char* filter = argc > 1 ? argv[1] : "";
+    unsigned long long* stamps; float* out; unsigned *src, *dst;
+    CK(hipMalloc(&stamps, 2048 * 16)); CK(hipMalloc(&out, 4096));
+    CK(hipMalloc(&src, (size_t)1 << 30)); CK(hipMalloc(&dst, (size_t)1 << 30));
+    { std::vector<unsigned> h((size_t)1 << 22); unsigned s = 12345u; for (auto& v : h) { s = s * 1664525u + 1013904223u; v = s; }
+      for (size_t o = 0; o < ((size_t)1 << 30); o += h.size() * 4) CK(hipMemcpy((char*)src + o, h.data(), h.size() * 4, hipMemcpyHostToDevice)); }
+    hipLaunchKernelGGL(k_check, dim3(1), dim3(1), 0, 0, out);
+    float chk[6]; CK(hipMemcpy(chk, out, sizeof chk, hipMemcpyDeviceToHost));
+    printf("check: mul_sdwa bytes -> %.4f %.4f %.4f (want 0.25 32 63.75); pknorm -> %.0f %.0f (want 51379 3327|3328); fma_mix f16 denormal -> %.2f (want 55.5)\n",
+           chk[0], chk[1], chk[2], chk[3], chk[4], chk[5]);
+    const double I8 = 8.0 * ITERS;
+    Case cases[] = {
+        {"idle (s_sleep)", k_idle, 0, 0},
+        {"v_fma_f32", k_fma_f32, I8, 0}, {"v_fmac_f32", k_fmac_f32, I8, 0}, {"v_add_f32", k_add_f32, I8, 0}, {"v_sub_f32", k_sub_f32, I8, 0}, {"v_mul_f32", k_mul_f32, I8, 0},
+        {"v_max_f32", k_max_f32, I8, 0}, {"v_mul_f32_sdwa b1", k_mul_sdwa, I8, 0}, {"v_add_f32_sdwa b1", k_add_sdwa, I8, 0},
+        {"v_pk_fma_f32", k_pk_fma, I8, 0}, {"v_pk_mul_f32", k_pk_mul, I8, 0}, {"v_fma_mix_f32", k_fma_mix, I8, 0}, {"v_dot2_f32_f16", k_dot2_f16, I8, 0},
+        {"v_mov_b32", k_mov_b32, I8, 0}, {"v_add_u32", k_add_u32, I8, 0}, {"v_and_b32", k_and_b32, I8, 0}, {"v_lshlrev_b32", k_lshl_b32, I8, 0},
+        {"v_lshl_add_u32", k_lshl_add, I8, 0}, {"v_mul_u32_u24", k_mul_u24, I8, 0}, {"v_mad_u32_u24", k_mad_u24, I8, 0}, {"v_perm_b32", k_perm, I8, 0},
+        {"v_alignbyte_b32", k_alignbyte, I8, 0}, {"v_and_or_b32", k_and_or, I8, 0}, {"v_bfe_u32", k_bfe, I8, 0}, {"v_cndmask_b32", k_cndmask, I8, 0},
+        {"v_cvt_f32_ubyte1", k_cvt_ubyte, I8, 0}, {"v_cvt_f32_u32", k_cvt_u32, I8, 0}, {"v_cvt_pk_u8_f32", k_cvt_pk_u8, I8, 0}, {"v_cvt_pknorm_u16", k_cvt_pknorm, I8, 0},
+        {"v_fma_f64", k_fma_f64, I8, 0}, {"v_add_f64", k_add_f64, I8, 0}, {"v_mul_f64", k_mul_f64, I8, 0}, {"v_rcp_f64", k_rcp_f64, I8, 0},
+        {"ds_read_b32 s1", k_lds<1, 0>, I8, 0}, {"ds_read_b32 s4", k_lds<4, 0>, I8, 0}, {"ds_read2_b32 s1", k_lds<1, 1>, I8, 0}, {"ds_read2_b32 s4", k_lds<4, 1>, I8, 0},
+        {"ds_read_b64 s2", k_lds<2, 2>, I8, 0}, {"ds_read_b64 s8", k_lds<8, 2>, I8, 0}, {"ds_read_b128 s4", k_lds<4, 3>, I8, 0},
+        {"ds_write_b32 s1", k_lds<1, 4>, I8, 0}, {"ds_write_b128 s4", k_lds<4, 5>, I8, 0},
+        {"gload L2 dword", k_gload_l2<4>, 2.0 * ITERS, 0}, {"gload L2 dwordx3", k_gload_l2<12>, 2.0 * ITERS, 0}, {"gload L2 dwordx4", k_gload_l2<16>, 2.0 * ITERS, 0},
+        {"stream read 16B", k_stream_read, 0, 4.0 * (double)((size_t)1 << 30)}, {"stream write 16B", k_stream_write, 0, 4.0 * (double)((size_t)1 << 30)},
+    };
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int blocks = 256 * 8;
+    printf("%-20s %9s %7s %8s %7s %9s\n", "case", "ms", "MHz", "cyc/inst", "watts", "nJ/winst");
+    for (auto& c : cases) {
+        if (*filter && !strstr(c.name, filter)) continue;
+        std::vector<double> watts; g_stop = false;
+        float ms = 0;
+        hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, stamps, out, 1u, src, dst);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0)); hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, stamps, out, 1u, src, dst); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        const int warm = (int)(700.0 / ms) + 1, reps = (int)(1800.0 / ms) + 1;
+        for (int i = 0; i < warm; ++i) hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, stamps, out, 1u, src, dst);
+        CK(hipDeviceSynchronize());
+        std::thread th(sampler, &watts);
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(c.k, dim3(blocks), dim3(256), 0, 0, stamps, out, 1u, src, dst);
+        CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        g_stop = true; th.join();
+        CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+        unsigned long long h[4096]; CK(hipMemcpy(h, stamps, sizeof h, hipMemcpyDeviceToHost));
+        double cyc = 0, tick = 0; for (int b = 0; b < 2048; ++b) { cyc += (double)h[2 * b]; tick += (double)h[2 * b + 1]; }
+        const double mhz = 100.0 * cyc / tick;
+        // the median of the samples taken in the second half of the run (the first ones still see the previous case)
+        double w = 0; if (watts.size() > 2) { std::vector<double> v(watts.begin() + watts.size() / 2, watts.end()); std::sort(v.begin(), v.end()); w = v[v.size() / 2]; }
+        const double cpi = c.inst_per_wave > 0 ? ms * 1e-3 * mhz * 1e6 / (8.0 * c.inst_per_wave) : 0;
+        // energy above the idle floor per wave-instruction: (W - 245) * time / (1024 SIMDs * 8 waves * instructions)
+        const double nj = c.inst_per_wave > 0 ? (w - 245.0) * ms * 1e-3 / (1024.0 * 8.0 * c.inst_per_wave) * 1e9 : 0;
+        printf("%-20s %9.4f %7.0f %8.2f %7.0f %9.3f", c.name, ms, mhz, cpi, w, nj);
+        if (c.bytes > 0) printf("   %6.0f GB/s  %.3f nJ/byte above idle", c.bytes / ms / 1e6, (w - 245.0) * ms * 1e-3 / c.bytes * 1e9);
+        printf("\n"); fflush(stdout);
+    }
+    return 0;
+}

@@ -1,10 +1,13 @@
 """Developer probe: time the uint8 bilinear warp of the BASELINE workload per kernel kind (rwh_lab_tune).
-   python tools/warp_quick.py [kinds...]      kinds: 0 auto, 5/6/7 wave-private patches, 22/23 tile kernel"""
+   python tools/warp_quick.py [kinds...]      kinds: 0 = the library's own choice, 5/6/7 = patch width 32/64/128 (default: 0 5 6 7)
+   RWH_LIB=<path to another build of librwh_hip.so> (ablation builds), N=<timed launches>; prints the shader clock the
+   chip held during the timed launches (rwh_lab_clock_probe)."""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_with_homography_amd import _lib, kernels
 from ransac_with_homography_amd import homography as hg
+if os.environ.get("RWH_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["RWH_LIB"])
 H_S = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
 if "ROT" in os.environ or "SCALE" in os.environ:      # rotation by ROT degrees / zoom by SCALE about the image centre instead
     t, sc = np.deg2rad(float(os.environ.get("ROT", "0"))), float(os.environ.get("SCALE", "1"))
@@ -23,19 +26,40 @@ inv = np.linalg.inv(H_S)
 out = torch.empty((frames, oh, ow, 3), dtype=torch.uint8, device=dev)
 lib = _lib.load()
 ref = None
-for kind in [int(a) for a in sys.argv[1:]] or [6, 22, 23]:
+for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
     assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, kind) == 0
     for _ in range(60): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = int(os.environ.get("N", "200"))
+    probe = kernels.ClockProbe(0.6 * n * 0.45 * frames / 32)      # ends inside the timed launches
     e0.record()
-    n = 40
     for _ in range(n): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / n
     by = frames * (Hh * W * 3 + oh * ow * 3)
     same = "" if ref is None else (" identical to first kind: %s" % bool(torch.equal(ref, out)))
     if ref is None: ref = out.clone()
+    import hashlib
+    digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12] if os.environ.get("SHA") else ""
     plan = kernels.warp_plan((frames, Hh, W, 3), torch.uint8, inv, grid, (Hh, W), "bilinear", torch.uint8)
+    watts = ""
+    if os.environ.get("POWER"):          # POWER=1: 3 more seconds of back-to-back launches with rocm-smi sampled meanwhile
+        import subprocess, threading, time, re
+        samples, stop = [], threading.Event()
+        def sampler():
+            while not stop.is_set():
+                o = subprocess.run("rocm-smi --showpower", shell=True, capture_output=True, text=True).stdout
+                m = re.search(r"Power \(W\): ([0-9.]+)", o)
+                if m: samples.append(float(m.group(1)))
+        th = threading.Thread(target=sampler); th.start()
+        t_end = time.time() + 3.0
+        p2 = kernels.ClockProbe(1500.0)
+        while time.time() < t_end:
+            for _ in range(200): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
+            torch.cuda.synchronize()
+        stop.set(); th.join()
+        tail = sorted(samples[len(samples) // 2:])
+        watts = "  power %.0f W (median of %d samples, max %.0f) sclk(1.5 s) %.0f MHz" % (tail[len(tail) // 2] if tail else 0, len(tail), max(samples or [0]), p2.mhz())
     print(plan, end="  ")
-    print("kind %2d  %.4f ms per %d frames = %.2f us/frame  %.0f GB/s = %.3f of 8 TB/s%s" % (kind, ms, frames, ms * 1e3 / frames, by / ms / 1e6, by / ms / 1e6 / 8000, same), flush=True)
+    print("kind %2d  %.4f ms per %d frames = %.2f us/frame  %.0f GB/s = %.3f of 8 TB/s  sclk %.0f MHz%s" % (kind, ms, frames, ms * 1e3 / frames, by / ms / 1e6, by / ms / 1e6 / 8000, probe.mhz(), same) + watts + (" sha1 " + digest if digest else ""), flush=True)
