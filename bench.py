@@ -141,6 +141,46 @@ class GpuBackend:
         torch = self.torch
         return torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
+    def clock_probe(self, ms):
+        """One wavefront on a side stream that counts shader cycles for `ms` ms (rwh_lab_clock_probe): .mhz() afterwards."""
+        return self.kernels.ClockProbe(ms)
+
+    def load_facts(self, step, seconds=1.2):
+        """What the chip does under `seconds` of back-to-back step() launches: the shader clock it holds (in-kernel cycle
+        counter against the 100 MHz constant clock) and the board power rocm-smi reports meanwhile, against the power cap.
+        MI355X lowers its clock when a kernel reaches the cap; then the kernel's bound is energy per pixel."""
+        import re
+        import threading
+        samples, stop = [], threading.Event()
+
+        def smi(args):
+            try:
+                return subprocess.run(["rocm-smi"] + args, capture_output=True, text=True, timeout=5).stdout
+            except Exception:
+                return ""
+
+        def sampler():
+            while not stop.is_set():
+                m = re.search(r"Power \(W\):\s*([0-9.]+)", smi(["--showpower"]))
+                if m:
+                    samples.append(float(m.group(1)))
+                else:
+                    time.sleep(0.05)
+        th = threading.Thread(target=sampler)
+        th.start()
+        t_end = time.perf_counter() + seconds
+        probe = self.clock_probe(min(1000.0 * seconds * 0.6, 1500.0))
+        while time.perf_counter() < t_end:
+            for _ in range(50):
+                step()
+            self.sync()
+        stop.set()
+        th.join()
+        cap = re.search(r"Max Graphics Package Power \(W\):\s*([0-9.]+)", smi(["--showmaxpower"]))
+        tail = sorted(samples[len(samples) // 2:])
+        return {"sclk_mhz": round(probe.mhz(), 0), "power_w": tail[len(tail) // 2] if tail else None,
+                "power_cap_w": float(cap.group(1)) if cap else None, "power_samples": len(tail)}
+
     # ---- RANSAC workloads ----
     def _matches(self):
         z = np.load(os.path.join(ROOT, "tests", "golden", "matchespoints.npz"))
@@ -237,6 +277,35 @@ def _scaling_set_leg(self, sync_all):
     return {"scaling_set": report}
 
 
+def _parity_path_leg(self):
+    """`RANSAC.run` end to end -- the path that carries the bit-exact guarantee (winner, count, inlier list equal the
+    reference's): numpy sampling, uploads, K1 + K2, the reference's own SVD on the host for every sample K1 flags (repeated
+    index: 3.3 %; ill-conditioned: ~2 %) and for every hypothesis near the decision, K2 on those, the accept rules, the host
+    refit.  The host SVDs are LAPACK dgesdd calls of ~8 us each that OpenBLAS serialises: they are the cost."""
+    import ransac as rs
+    z = np.load(os.path.join(ROOT, "tests", "golden", "matchespoints.npz"))
+    X, Y = z["ptsA"].T.copy(), z["ptsB"].T.copy()
+    out = {}
+    for K, reps in ((1000, 10), (10000, 5), (100000, 2)):
+        def run():
+            np.random.seed(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                r = rs.RANSAC(rs.HomoModel(th=5, d=70, n=4), k=K)
+                return r, r.run([X, Y], method="fwd")
+        run()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            r, (H, inl, cnt) = run()
+        t = (time.perf_counter() - t0) / reps
+        out["K=%d" % K] = {"ms_per_run": round(t * 1e3, 3), "hyp_per_s": round(K / t, 1), "winner": r.last_run["winner"], "inliers": int(cnt),
+                           "host_solved_hypotheses": r.last_run.get("host_settled"), "host_rounds": r.last_run.get("host_rounds"),
+                           "flagged_by_k1": r.last_run.get("flagged")}
+    out["note"] = ("RANSAC.run: bit-exact inlier sets (tests: 19 reference runs + g10 + g12).  The K=... entries beside this one "
+                   "time rwh_ransac_search alone (K1 + K2 + argmax + 16-byte readback): the raw search, no host solver.")
+    return out
+
+
+GpuBackend.parity_path_leg = _parity_path_leg
 GpuBackend.scaling_set_leg = _scaling_set_leg
 GpuBackend.other_kernels_leg = lambda self, w, h, nb: _other_kernels_leg(self, w, h, nb)
 GpuBackend.config4_leg = lambda self: _config4_leg(self)
@@ -294,6 +363,7 @@ def run_rank(args, backend, dist=None):
     elapsed = max_over_ranks(elapsed)
     value = world * B * out_h * out_w / 1e6 * args.steps / elapsed
     alg_bytes = B * (3 * src_h * src_w + 3 * out_h * out_w)
+    load = backend.load_facts(step) if (rank == 0 and hasattr(backend, "load_facts")) else {}
     del keep, step
 
     extras = {}
@@ -352,7 +422,13 @@ def run_rank(args, backend, dist=None):
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "algorithmic_bytes_per_launch": alg_bytes,
             "kernel_ms": round(kernel_ms, 4),
             "read_only_frac": round(B * 3 * src_h * src_w / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-    roof.update(profile_facts(plan, B, (src_w, src_h), kernel_ms))
+    roof.update(profile_facts(plan, B, (src_w, src_h), kernel_ms, load.get("sclk_mhz")))
+    roof.update(load)
+    if load.get("power_w") and load.get("power_cap_w") and load["power_w"] >= 0.97 * load["power_cap_w"]:
+        # the launches run AT the board's power cap and the chip holds a clock below its 2.4 GHz maximum: the bound that
+        # binds is energy per pixel (HBM 41 %, VALU 45 %, LDS 10 % of the energy of a launch)
+        roof["limiter"] = ("board power cap: %.0f W of %.0f W, shader clock held at %.0f MHz of 2400; " % (load["power_w"], load["power_cap_w"], load["sclk_mhz"])
+                           + (roof.get("limiter") or ""))
     line = {
         "metric": "backward-warp Mpixels/sec (+ RANSAC hypotheses/sec)", "value": round(value, 1), "unit": "Mpix/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -373,23 +449,37 @@ def run_rank(args, backend, dist=None):
     return line
 
 
-def profile_facts(kernel, frames, src_wh, kernel_ms):
+PMC_JSON = "profiles/r03_pmc.json"
+
+
+def profile_facts(kernel, frames, src_wh, kernel_ms, sclk_mhz=None):
     """Counter-derived facts of the dominant kernel from the committed rocprofv3 PMC summary of THIS command
-    (profiles/r02_pmc.json; counters cannot be read from inside the run): HBM traffic per launch and the VALU share."""
-    path = os.path.join(ROOT, "profiles", "r02_pmc.json")
+    (PMC_JSON; counters cannot be read from inside the run): HBM traffic per launch and the VALU roofline --
+    `valu`: VALU instructions per output pixel (SQ_INSTS_VALU / waves / 512 px x 64 lanes = lane-instructions per pixel)
+    against 1024 SIMDs x 16 lanes x the shader clock MEASURED IN THIS RUN (every VALU instruction of this kernel's mix
+    issues in >= 4 cycles per wavefront; only plain float32 / 32-bit integer adds, multiplies and moves take 2)."""
+    path = os.path.join(ROOT, PMC_JSON)
     if not os.path.exists(path):
         return {}
     p = json.load(open(path)).get(kernel)
     if not p or tuple(p.get("src", ())) != tuple(src_wh):
         return {}
     out = {"traffic": int(p["hbm_bytes_per_launch"] * frames / p["frames"]) if p.get("hbm_bytes_per_launch") else None,
-           "traffic_source": "profiles/r02_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
+           "traffic_source": PMC_JSON + " (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command)"}
     if p.get("valu_insts_per_wave"):
         # instructions x measured issue cost / kernel cycles: waves per SIMD x instructions per wave x cycles per wave-
         # instruction (tools/valu_rates, this kernel's mix), against the kernel time of THIS run at the PMC pass's clock
         waves_per_simd = p["waves_per_launch"] * frames / p["frames"] / 1024.0
         cyc = waves_per_simd * p["valu_insts_per_wave"] * p["cycles_per_valu_inst"]
         out["valu_frac"] = round(cyc / (kernel_ms * 1e-3 * p["sclk_hz"]), 4)
+        if sclk_mhz:
+            waves = p["waves_per_launch"] * frames / p["frames"]
+            lane_insts = waves * p["valu_insts_per_wave"] * 64.0
+            peak = 1024 * 16 * sclk_mhz * 1e6
+            out["valu"] = {"insts_per_wave": p["valu_insts_per_wave"], "lane_insts_per_pixel": round(p["valu_insts_per_wave"] / 8.0, 2),
+                           "achieved": round(lane_insts / (kernel_ms * 1e-3) / 1e12, 2), "peak": round(peak / 1e12, 2),
+                           "unit": "T lane-instructions/s at the measured %.0f MHz" % sclk_mhz,
+                           "frac": round(lane_insts / (kernel_ms * 1e-3) / peak, 4)}
         out["valu_frac_pmc"] = p.get("valu_busy_frac")
         out["ta_busy_frac_pmc"] = p.get("ta_busy_frac")
         out["valu_insts_per_wave"] = p["valu_insts_per_wave"]
@@ -466,6 +556,8 @@ def ransac_legs(backend, dist, world, rank, sync_all, max_over_ranks):
             entry["all_ranks_decoded"] = [int(v) for v in t.tolist()]
         report["K=%d" % K] = entry
 
+    if world == 1 and hasattr(backend, "parity_path_leg"):
+        report["parity_path"] = backend.parity_path_leg()
     if world == 1:
         report.update(backend.batched_search_leg(sync_all))
         if hasattr(backend, "scaling_set_leg"):

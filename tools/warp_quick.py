@@ -42,6 +42,8 @@ for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
     if ref is None: ref = out.clone()
     import hashlib
     digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12] if os.environ.get("SHA") else ""
+    import hashlib
+    digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12] if os.environ.get("SHA") else ""      # SHA=1: digest of the output
     plan = kernels.warp_plan((frames, Hh, W, 3), torch.uint8, inv, grid, (Hh, W), "bilinear", torch.uint8)
     watts = ""
     if os.environ.get("POWER"):          # POWER=1: 3 more seconds of back-to-back launches with rocm-smi sampled meanwhile
