@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
             const int local = hyp - stop_p * k_per;
             if (done != 0ull && (long long)(0xFFFFFFFFull - done) < (long long)local) {      // an earlier hypothesis already exits
                 if (lane == 0) counts[hyp] = -1;
-                if (masks && lane < mask_stride) masks[(size_t)hyp * mask_stride + lane] = 0;
+                if (masks)
+                    for (int w = lane; w < mask_stride; w += 64) masks[(size_t)hyp * mask_stride + w] = 0;   // every word (M > 4096: more than 64)
                 continue;
             }
         }

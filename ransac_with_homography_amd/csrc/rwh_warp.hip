@@ -249,7 +249,9 @@ __device__ __forceinline__ void sample_exact(const unsigned char* simg, size_t i
                                              double sx, double sy, DstT* out) {
     if constexpr (INTERP == RWH_NEAREST) {
         const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
-        const bool valid = (xi >= 0) & (xi <= bound_w - 1) & (yi >= 0) & (yi <= bound_h - 1);
+        // numpy's astype(int32) turns NaN into INT_MIN, which the reference then masks (homography.py:117); the GPU's
+        // conversion gives 0 for NaN, so a NaN coordinate is masked explicitly (+-inf saturate to a masked value either way)
+        const bool valid = (xi >= 0) & (xi <= bound_w - 1) & (yi >= 0) & (yi <= bound_h - 1) & (sx == sx) & (sy == sy);
         if (valid) {
             const size_t off = ((size_t)yi * (size_t)src_w + (size_t)xi) * (size_t)(C * sizeof(SrcT));
             const SrcT* p = reinterpret_cast<const SrcT*>(simg + off);

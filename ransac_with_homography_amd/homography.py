@@ -30,7 +30,7 @@ import os
 
 import numpy as np
 
-from . import _lib, kernels
+from . import _lib, _xfer, kernels
 
 # Which warp kernels serve this module:
 #   EXACT = None (default)  numpy arrays in  -> the float64 "exact" kernel: results bit-identical to the reference's
@@ -154,7 +154,7 @@ def _to_device(img):
     if a.shape[2] not in (3, 4):
         raise IndexError("index out of bounds: the warp supports 3 or 4 channels")
     src = a if a.dtype in (np.uint8, np.float32) else a.astype(np.float32)
-    return torch.from_numpy(np.ascontiguousarray(src)).to(dev), True, a.dtype
+    return _xfer.to_device(src, dev), True, a.dtype
 
 
 def _warp(img, H, grid, bound_hw, convert, u8_out):
@@ -175,7 +175,7 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
     if not was_numpy:
         return out
     _blank_origin(img)
-    res = out.cpu().numpy()
+    res = _xfer.to_host(out)
     if convert == "nn":
         return res if res.dtype == np_dtype else res.astype(np_dtype)
     return res if (u8_out or res.dtype == np.float64) else res.astype(np.float64)  # the reference's bilinear yields float64
@@ -423,8 +423,8 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
         if blending:
             t_dev = t_dev.clone()      # addAlpha copies: the caller's imgT keeps its texel (0,0)
     else:
-        t_dev = torch.from_numpy(np.ascontiguousarray(imgT)).to(dev)
-        q_dev = torch.from_numpy(np.ascontiguousarray(imgQ)).to(dev)
+        t_dev = _xfer.to_device(imgT, dev)      # staged through page-locked buffers by several host threads (_xfer)
+        q_dev = _xfer.to_device(imgQ, dev)
     exact = (not tens) if EXACT is None else bool(EXACT)    # numpy in: the bit-identical float64 kernel; tensors in: the fast one
     mode = 0 if paste else 1 if blending == 'Rate' else 2   # 'Gradient': the alpha ramp, exact kernel only
     out = kernels.stitch_panorama(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), (fh, fw),
@@ -433,7 +433,7 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
         return out
     if not blending:
         _blank_origin(imgT)            # transformImageH -> bilinear blanks the caller's texel (0,0) in the paste path
-    return out.cpu().numpy()
+    return _xfer.to_host(out)
 
 
 def cylindericlMap(img, f=1600):

@@ -53,7 +53,7 @@ class CpuStandIn:
         rows = (0, out_h) if rows_of is None else self.sharded.shard_range(out_h, *rows_of)
         return (lambda: time.sleep(2e-4)), out_h, out_w, rows, "stand-in", None
 
-    def make_search(self, K, b, e):
+    def make_search(self, K, b, e, settle=False):
         counts = np.load(os.path.join(ROOT, "tests", "golden", "g10_config5_search.npz"))["counts"].astype(np.int64)
         assert K == counts.size
         need = self.kernels.need_count(185, 70, 4)

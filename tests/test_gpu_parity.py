@@ -596,6 +596,21 @@ def test_batched_early_stop_and_device_handoff(gpu, matches):
         scored = (stop.counts >= 0)
         assert torch.equal(stop.counts[scored], full.counts[scored]) and torch.equal(stop.masks[scored], full.masks[scored])
         assert not stop.masks[~scored].any()
+        if expect_exit:
+            # problems with more than 4 096 correspondences (mask rows longer than one wavefront: the general scorer) into
+            # a buffer full of ones: every word of a skipped hypothesis must come back zero
+            big = [np.concatenate([X] * 40, axis=1) for X, _ in probs[:2]], [np.concatenate([Y] * 40, axis=1) for _, Y in probs[:2]]
+            bs = [x.shape[1] for x in big[0]]
+            assert min(bs) > 4096
+            boffs = torch.tensor(np.concatenate([[0], np.cumsum(bs)]), dtype=torch.int32, device=gpu)
+            bpa = torch.from_numpy(np.concatenate([np.ascontiguousarray(x.T[:, :2], np.float32) for x in big[0]])).to(gpu)
+            bpb = torch.from_numpy(np.concatenate([np.ascontiguousarray(y.T[:, :2], np.float32) for y in big[1]])).to(gpu)
+            bneeds = torch.tensor([kernels.need_count(m, d, 4) for m in bs], dtype=torch.int32, device=gpu)
+            bws = kernels.BatchWorkspace(2, 16384, max(bs), gpu)      # enough hypotheses that late waves start after the first exit
+            bws.masks.fill_(-1)
+            kernels.ransac_batched(bpa, bpb, boffs, bneeds, 5.0, "fwd", bws, seed=seed, early_stop=True)
+            skipped = bws.counts < 0
+            assert bws.masks.shape[2] > 64 and bool(skipped.any()) and not bws.masks[skipped].any()
         best = full.best.cpu().numpy()
         for p in range(len(probs)):
             w, _, early = kernels.decode_best(best[p], K)
@@ -880,6 +895,18 @@ def test_convertfunc_on_precomputed_coordinates(gpu, chn):
     z[0, 40:80] = np.arange(40) + 0.5; z[1, 40:80] = (np.arange(40) % (h - 1)) + 0.5  # nearest-neighbour ties
     z[0, 80:90] = w - 1 - 1e-9; z[1, 90:100] = h - 1 - 1e-9                            # just inside the last column / row
     z[0, 100:105] = -1e-12; z[1, 105:110] = h - 1 + 1e-12                             # just outside
+    # non-finite coordinates with the other one in range: numpy's astype(int32) makes INT_MIN of them -> masked (nn), and the
+    # float comparisons of bilinear's mask are False for NaN ... which the reference then indexes with: keep those for nn only
+    z_nn = z.copy()
+    z_nn[0, 110:114] = np.nan; z_nn[1, 110:114] = 5.0
+    z_nn[1, 114:118] = np.nan; z_nn[0, 114:118] = 7.0
+    z_nn[0, 118:120] = np.inf; z_nn[1, 118:120] = 3.0; z_nn[0, 120:122] = -np.inf; z_nn[1, 120:122] = 3.0
+    for img in (img8, imgf):
+        with np.errstate(all="ignore"):
+            zr, zg, ir, ig = z_nn.copy(), z_nn.copy(), img.copy(), img.copy()
+            ref = orc.nearest_neighbor(zr, ir, h, w, mh, mw)
+            got = hg.convertfunc["nn"](zg, ig, h, w, mh, mw)
+        assert np.array_equal(got, ref) and not got.reshape(-1, chn)[110:122].any()        # every one of them is masked
     for img in (img8, imgf):
         for conv, ofn in (("nn", orc.nearest_neighbor), ("bilinear", orc.bilinear)):
             zr, zg, ir, ig = z.copy(), z.copy(), img.copy(), img.copy()
@@ -1550,3 +1577,24 @@ def test_ransac_run_n6_vs_reference(gpu, matches):
         from oracle import rwh_oracle as orc
         Hs, counts = orc.ransac_table(ptsA.T, ptsB.T, idx[p][:, :4], th=5, method="fwd")
         assert int(res[p][2]) == int(counts.max())
+
+
+def test_host_transfer_pipeline_round_trip(gpu):
+    """_xfer: the chunked, page-locked, multi-threaded upload / download used by the numpy-facing API moves every byte
+    (sizes around the chunk boundaries, uint8 and float32, back-to-back calls re-using the staging ring)."""
+    from ransac_with_homography_amd import _xfer
+    rng = np.random.default_rng(3)
+    for shape, dt in (((1000, 1371, 3), np.uint8), ((2 * _xfer.CHUNK + 5,), np.uint8), ((7 * _xfer.CHUNK,), np.uint8),
+                      ((701, 1203, 4), np.float32), ((13 * _xfer.CHUNK // 4 + 3,), np.float32), ((100, 100, 3), np.uint8)):
+        a = rng.integers(0, 255, shape).astype(dt)
+        t = _xfer.to_device(a, gpu)
+        assert tuple(t.shape) == shape and torch.equal(t.cpu(), torch.from_numpy(a))
+        b = _xfer.to_host(t + 1 if dt == np.float32 else t)
+        assert b.dtype == dt and b.shape == shape and np.array_equal(b, a + 1 if dt == np.float32 else a)
+        c = _xfer._to_host_staged(t.contiguous()) if a.nbytes >= _xfer.MIN_BYTES else b      # the pageable fallback of to_host
+        assert c.dtype == dt and c.shape == shape and (c is b or np.array_equal(c, a)) and b.flags.writeable
+    # a kernel's result read back right after the launch: the download waits for the producer stream
+    src = torch.randint(0, 256, (2160, 3840, 3), dtype=torch.uint8, device=gpu)
+    for _ in range(3):
+        out = src.flip(0).contiguous()
+        assert np.array_equal(_xfer.to_host(out), src.cpu().numpy()[::-1])

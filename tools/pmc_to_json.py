@@ -1,4 +1,4 @@
-"""Turn the summary of tools/pmc_pass.sh (summary.json + the kernel traces of its passes) into profiles/r02_pmc.json's two
+"""Turn the summary of tools/pmc_pass.sh (summary.json + the kernel traces of its passes) into profiles/r03_pmc.json's two
 entries for the headline kernel (4K x 32 and 8K x 8 launches).  usage: python tools/pmc_to_json.py <pmc dir> <out json>"""
 import csv, glob, json, os, statistics, sys
 root, out = sys.argv[1], sys.argv[2]

@@ -59,7 +59,7 @@ for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
         p2 = kernels.ClockProbe(1500.0)
         while time.time() < t_end:
             for _ in range(200): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
-            torch.cuda.synchronize()
+            torch.cuda.current_stream().synchronize()      # not the device: that would wait for the clock probe
         stop.set(); th.join()
         tail = sorted(samples[len(samples) // 2:])
         watts = "  power %.0f W (median of %d samples, max %.0f) sclk(1.5 s) %.0f MHz" % (tail[len(tail) // 2] if tail else 0, len(tail), max(samples or [0]), p2.mhz())
