@@ -1083,7 +1083,8 @@ __device__ __forceinline__ uint32_t nn_exact_texel(const FastArgs& a, const doub
     const double W = fma(ih[7], y, ih[6] * x) + ih[8];
     const double sx = X / W, sy = Y / W;
     const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
-    if (!((xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1))) return 0u;   // -> texel (0,0), blanked
+    // (numpy's astype(int32) turns a NaN into INT_MIN, which the reference masks; the GPU's conversion gives 0: masked explicitly)
+    if (!((xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1) & (sx == sx) & (sy == sy))) return 0u;   // -> texel (0,0), blanked
     const uint32_t off = ((uint32_t)yi * (uint32_t)a.src_w + (uint32_t)xi) * 3u;
     const uint32_t img_bytes = (uint32_t)a.src_h * (uint32_t)a.src_w * 3u;
     if (off + 4u <= img_bytes) return ld4(simg + off) & 0xFFFFFFu;
