@@ -132,6 +132,18 @@ def new_best(device):
     return torch.zeros(2, dtype=torch.int64, device=device)
 
 
+_scratch_best = {}
+
+
+def scratch_best(device):
+    """A 2 x int64 accumulator nobody reads (settle-step calls of K2 want counts and masks only): allocated once per device,
+    never cleared -- saves the zero-fill launch of `new_best` per call."""
+    key = (device.type, device.index)
+    if key not in _scratch_best:
+        _scratch_best[key] = torch.zeros(2, dtype=torch.int64, device=device)
+    return _scratch_best[key]
+
+
 def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=True, want_err=False):
     """Launch K2.  Returns (counts [K] int32, masks [K,ceil(M/64)] int64 or None, err [K,M] float32 or None);
     `best` (from new_best) is updated in place with atomic max."""
@@ -154,10 +166,17 @@ class SearchWorkspace:
     def __init__(self, k, m, device, want_masks=True):
         self.k, self.m = k, m
         self.H = torch.empty((k, 9), dtype=torch.float32, device=device)
-        self.flags = torch.empty((k,), dtype=torch.uint8, device=device)
-        self.counts = torch.empty((k,), dtype=torch.int32, device=device)
+        # counts (int32) and flags (uint8) share one buffer so that the host reads both back with ONE copy (`counts_flags`)
+        self.cf = torch.empty((5 * k + 16,), dtype=torch.uint8, device=device)
+        self.counts = self.cf[:4 * k].view(torch.int32)
+        self.flags = self.cf[4 * k:5 * k]
         self.masks = torch.empty((k, (m + 63) // 64), dtype=torch.int64, device=device) if want_masks else None
         self.best = torch.zeros(2, dtype=torch.int64, device=device)
+
+    def counts_flags(self):
+        """-> (counts int32 [k], flags uint8 [k]) as host arrays, one device-to-host copy."""
+        raw = self.cf.cpu().numpy()
+        return raw[:4 * self.k].view(np.int32), raw[4 * self.k:5 * self.k]
 
 
 def ransac_search(pts_a, pts_b, idx, th, loss, need, ws, hyp_base=0, reset_best=True):

@@ -156,7 +156,7 @@ def presettle(pa_dev, pb_dev, pa, pb, idx_host, rows, th, method):
         return None
     H = svd_hypotheses(pa, pb, idx_host[rows][:, :4])
     hd = torch.from_numpy(H).to(pa_dev.device)
-    cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.new_best(pa_dev.device))
+    cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.scratch_best(pa_dev.device))
     return rows, H, cnt, msk
 
 
@@ -199,7 +199,7 @@ def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, m
         n_rounds += 1
         H = svd_hypotheses(pa, pb, idx_host[cand][:, :4])
         hd = torch.from_numpy(H).to(pa_dev.device)
-        cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.new_best(pa_dev.device))
+        cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.scratch_best(pa_dev.device))
         counts[cand] = cnt.cpu().numpy()
         st.add(cand, H, msk)
     if stats is not None:
@@ -361,9 +361,14 @@ class RANSAC(object):
         idx_host = np.random.randint(0, mx, (k, self.n))
 
         pa_host, pb_host = _points_rows(X), _points_rows(Y)
-        pa = torch.from_numpy(pa_host).to(dev)
-        pb = torch.from_numpy(pb_host).to(dev)
-        idx = torch.from_numpy(np.ascontiguousarray(idx_host[:, :4], dtype=np.int32)).to(dev)
+        # one upload for the correspondences and the index table (three small copies cost ~20 us each)
+        idx32 = np.ascontiguousarray(idx_host[:, :4], dtype=np.int32)
+        blob = torch.from_numpy(np.concatenate([pa_host.reshape(-1).view(np.uint8), pb_host.reshape(-1).view(np.uint8),
+                                                idx32.reshape(-1).view(np.uint8)])).to(dev)
+        nb = 8 * mx
+        pa = blob[:nb].view(torch.float32).reshape(mx, 2)
+        pb = blob[nb:2 * nb].view(torch.float32).reshape(mx, 2)
+        idx = blob[2 * nb:].view(torch.int32).reshape(k, 4)
         ws = kernels.SearchWorkspace(k, mx, dev)
         need_i = kernels.need_count(mx, self.d, self.n)
         th = _weak_threshold(self.th)
@@ -371,8 +376,7 @@ class RANSAC(object):
         # while the GPU searches: the reference's solver for the samples the host already knows K1 will flag
         pre = presettle(pa, pb, pa_host, pb_host, idx_host, np.flatnonzero(repeated_rows(idx_host)), th, method)
         Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
-        both = torch.cat([counts, flags.to(torch.int32)]).cpu().numpy()        # one readback for counts + flags
-        counts_host, flags_host = both[:k], both[k:].astype(np.uint8)
+        counts_host, flags_host = ws.counts_flags()                           # one readback for counts + flags
         stats = {"raw_counts": counts_host.copy()}           # K2 on K1's own H, before the settle step
         winner, early, totalfit, mask_words, settled_rows, counts_host = _settle_on_host(
             pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need_i, th, method,

@@ -36,16 +36,18 @@ def gpu_score_slice(pa, pb, idx_slice, th, loss, need, hyp_base):
     Returns the slice's two packed keys (include/rwh.h, rwh_score_count) as a 2 x int64 tensor on the GPU."""
     import torch
     from . import kernels
-    from .ransac import RESCORE_MARGIN, _settle_on_host
+    from .ransac import RESCORE_MARGIN, _settle_on_host, presettle, repeated_rows
     k = idx_slice.shape[0]
     w0 = w1 = 0
     if k:
-        idx_host = np.ascontiguousarray(idx_slice, dtype=np.int32)
+        idx_host = np.ascontiguousarray(np.asarray(idx_slice)[:, :4], dtype=np.int32)
         ws = kernels.SearchWorkspace(k, pa.shape[0], pa.device, want_masks=False)
+        pa_host, pb_host = pa.cpu().numpy(), pb.cpu().numpy()          # (before the launch: a copy after it would wait for the search)
         kernels.ransac_search(pa, pb, torch.from_numpy(idx_host).to(pa.device), th, loss, need, ws, hyp_base=hyp_base)
-        winner, early, count, _, _, _ = _settle_on_host(pa, pb, pa.cpu().numpy(), pb.cpu().numpy(), idx_host,
-                                                        ws.counts.cpu().numpy(), ws.flags.cpu().numpy(), need, th, loss,
-                                                        RESCORE_MARGIN)
+        pre = presettle(pa, pb, pa_host, pb_host, idx_host, np.flatnonzero(repeated_rows(idx_host)), th, loss)   # while the GPU searches
+        counts_host, flags_host = ws.counts_flags()
+        winner, early, count, _, _, _ = _settle_on_host(pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need, th, loss,
+                                                        RESCORE_MARGIN, pre=pre)
         if winner is not None:
             inv = 0xFFFFFFFF - (hyp_base + winner)
             w0 = (int(count) << 32) | inv
