@@ -404,6 +404,10 @@ def ransac_run(X, Y, th=5, d=50, n=4, k=1000, method="reproj"):
         if cnt > best:
             best, best_mask, best_it = cnt, mask, it
     inliers = np.where(best_mask)
+    # HomoModel.fit's size check (ransac.py:38): exactly n columns, or more than n with collective=True -- a winner with
+    # fewer inliers than the sample size n (possible for n > 4: the model is fitted on four points) fails here
+    m = inliers[0].size
+    assert m == n or m > n, "invalid data size should be %d" % n
     Hf = fit_all(X[:, inliers[0]], Y[:, inliers[0]])
     return Hf, inliers, best, best_it
 

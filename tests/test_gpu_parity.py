@@ -1598,3 +1598,55 @@ def test_host_transfer_pipeline_round_trip(gpu):
     for _ in range(3):
         out = src.flip(0).contiguous()
         assert np.array_equal(_xfer.to_host(out), src.cpu().numpy()[::-1])
+
+
+def test_ransac_run_random_problem_families_vs_oracle(gpu):
+    """A short version of tools/soak_settle.py inside the suite: RANSAC.run against the oracle's sequential loop (same numpy
+    seed) on random lattice / cluster / contaminated / tiny / large-coordinate problems with random th, d, k, n and loss:
+    winner iteration, count, inlier list, the generator's position -- or the same failure (a winner with fewer inliers than
+    the refit accepts, ransac.py:38)."""
+    import contextlib
+    import io
+    import ransac as rs
+    from oracle import rwh_oracle as orc
+    rng = np.random.default_rng(2025)
+    Hs = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+
+    def project(G, noise):
+        P = np.concatenate([G, np.ones((len(G), 1))], 1) @ Hs.T
+        return P[:, :2] / P[:, 2:3] + rng.normal(0, noise, (len(G), 2))
+
+    for case in range(40):
+        kind = case % 4
+        if kind == 0:
+            M = int(rng.integers(30, 500)); G = np.stack([rng.integers(0, 12, M) * 37.0, rng.integers(0, 7, M) * 53.0], 1)
+        elif kind == 1:
+            M = int(rng.integers(30, 300)); c = rng.uniform(0, 2000, (5, 2)); G = c[rng.integers(0, 5, M)] + rng.normal(0, 0.01, (M, 2))
+        elif kind == 2:
+            M = int(rng.integers(5, 13)); G = rng.uniform(0, 500, (M, 2))
+        else:
+            M = int(rng.integers(50, 800)); G = rng.uniform(0, 1e4, (M, 2))
+        B = project(G, 0.7)
+        out = rng.random(M) < rng.choice([0.0, 0.3, 0.7])
+        B[out] = rng.uniform(0, float(np.abs(B).max()) + 1.0, (int(out.sum()), 2))
+        A, B = G.astype(np.float32), B.astype(np.float32)
+        th = float(rng.choice([1, 3, 5])); d = int(rng.choice([20, 50, 95])); k = int(rng.integers(40, 200)); n = int(rng.choice([4, 4, 6]))
+        m = str(rng.choice(["fwd", "backward", "reproj"])); seed = int(rng.integers(0, 1 << 30))
+        res = []
+        for runner in ("oracle", "gpu"):
+            np.random.seed(seed)
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                try:
+                    if runner == "oracle":
+                        H, inl, cnt, it = orc.ransac_run(A.T, B.T, th=th, d=d, n=n, k=k, method=m)
+                    else:
+                        r = rs.RANSAC(rs.HomoModel(th=th, d=d, n=n), k=k)
+                        H, inl, cnt = r.run([A.T, B.T], method=m)
+                        it = r.last_run["winner"]
+                    res.append((int(cnt), it, inl[0].tolist(), int(np.random.randint(0, 1 << 30))))
+                except (AssertionError, ValueError, TypeError, np.linalg.LinAlgError) as e:
+                    res.append(type(e).__name__)
+        if isinstance(res[0], str) or isinstance(res[1], str):
+            assert isinstance(res[0], str) and isinstance(res[1], str), (case, res)
+        else:
+            assert res[0] == res[1], (case, kind, M, th, d, k, n, m, seed, res[0][:2], res[1][:2])
