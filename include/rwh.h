@@ -271,6 +271,28 @@ RWH_API int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, con
                       void* dgesdd_ilp64, int threads, float* out_h);
 
 /*
+ * The host driver of RANSAC.run (ransac.py:159-213 up to, not including, the final refit) as ONE native call: upload,
+ * rwh_ransac_search, the settle step -- the reference's own solver (rwh_host_dlt4_svd) for every sample K1 flags and every
+ * hypothesis whose count is within min(margin_cap, 3 + count / 16) of a decision (the best count, `need`), re-scored by
+ * rwh_score_count; the repeated-index samples are solved on host threads while the GPU searches --, and the accept rules:
+ * the first hypothesis with count >= need wins and ends the search, else the first maximum.  Winner, count and inlier mask
+ * equal the reference loop's on the same index table (tests: every RANSAC fixture the reference produced).
+ *   pts_a, pts_b: m x 2 float32, idx: k x 4 int32 -- HOST arrays (the reference's inputs are host arrays; idx = the first
+ *   four columns of numpy's draws, ransac.py:177);
+ *   d_ws / h_ws: device workspace and PAGE-LOCKED host workspace of the sizes rwh_ransac_run_layout reports (offsets[11] and
+ *   offsets[19]); after the call d_ws holds K1's H (k x 9 float32 at offsets[3]), K2's counts (int32, offsets[4]), K1's flags
+ *   (offsets[5]) and the masks (offsets[6]); h_ws holds K2's raw counts (offsets[13]), the flags (offsets[14]) and the counts
+ *   after the settle step (offsets[15]);
+ *   out: 6 x int32 = winner index (-1: nothing ever scored > 0), early exit (0 / 1), winner's count, hypotheses solved on the
+ *   host, settle rounds, samples flagged by K1;  out_mask: ceil(m / 64) x uint64, the winner's inlier bitmask.
+ * Synchronises `stream` (its results are host values).  rwh_ransac_run_layout: fills offsets[0 .. 20), returns 20.
+ */
+RWH_API int rwh_ransac_run_layout(int m, int k, long long* offsets, int n_offsets);
+RWH_API int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const int32_t* idx, int k, double th, int loss,
+                   int need, int margin_cap, void* dgesdd_ilp64, int threads, void* d_ws, void* h_ws,
+                   int32_t* out, uint64_t* out_mask, void* stream);
+
+/*
  * Fused panorama compositor.  Replaces the body of stitchPanorama (homography.py:288-338) after its canvas
  * geometry (host, homography.py:303-321): addAlpha('Rate') + transformImageH + paste / alpha blend, in one pass
  * over the canvas, float64 arithmetic in the reference's order -> uint8 canvas bit-identical to the reference's.

@@ -18,7 +18,7 @@ def dgesdd_address():
         return _addr
     _addr = None
     try:
-        import numpy.linalg._umath_linalg  # noqa: F401  (maps numpy's LAPACK into the process)
+        import numpy.linalg._umath_linalg  # noqa: F401  (maps numpy's LAPACK into the process; the name `numpy` itself is unused)
         paths = set()
         with open("/proc/self/maps") as f:
             for line in f:

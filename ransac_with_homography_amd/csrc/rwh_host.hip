@@ -4,8 +4,11 @@
 // OpenBLAS the caller's numpy links (ransac_with_homography_amd/_lapack.py finds the symbol), called with numpy's own
 // arguments (jobz = 'A', column-major copy, workspace from a size query) -- so every H equals numpy's bit for bit
 // (tests/test_settle_cpu.py); what this file adds is the loop in native code, off the interpreter lock, on several cores.
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 #include "rwh.h"
@@ -47,6 +50,61 @@ void solve_range(dgesdd_t dgesdd, const float* pa, const float* pb, const int32_
 }
 }  // namespace
 
+// A small pool of host worker threads, started on first use and kept for the life of the process (the only state this
+// library keeps): starting a thread costs ~15-20 us, as much as two SVDs, and RANSAC.run asks for two batches of a few dozen
+// per call.  Chunks of a batch are handed out under a mutex; the caller works on chunks too and returns when all are done.
+class HostPool {
+  public:
+    static HostPool& get() { static HostPool* p = new HostPool; return *p; }     // never destroyed: workers may outlive main()
+    // run job(chunk) for chunk = 0 .. n_chunks-1 on up to `threads` threads (the caller included)
+    void run(int n_chunks, int threads, const std::function<void(int)>& job) {
+        std::lock_guard<std::mutex> serial(run_mu_);                            // one batch at a time
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            const int want = threads - 1 < n_chunks - 1 ? threads - 1 : n_chunks - 1;
+            while ((int)n_workers_ < want) { std::thread([this] { loop(); }).detach(); ++n_workers_; }
+            job_ = &job; n_chunks_ = n_chunks; next_ = 0; done_ = 0; limit_ = want; active_ = 0;
+        }
+        cv_work_.notify_all();
+        for (;;) {
+            int c;
+            { std::lock_guard<std::mutex> lk(mu_); if (next_ >= n_chunks_) break; c = next_++; }
+            job(c);
+            { std::lock_guard<std::mutex> lk(mu_); ++done_; }
+        }
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [this] { return done_ == n_chunks_; });
+        job_ = nullptr;
+    }
+
+  private:
+    void loop() {
+        for (;;) {
+            int c;
+            const std::function<void(int)>* job;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [this] { return job_ && next_ < n_chunks_ && active_ < limit_; });
+                c = next_++; job = job_; ++active_;
+            }
+            for (;;) {
+                (*job)(c);
+                std::lock_guard<std::mutex> lk(mu_);
+                ++done_;
+                if (next_ < n_chunks_) { c = next_++; continue; }
+                --active_;
+                if (done_ == n_chunks_) cv_done_.notify_all();
+                break;
+            }
+        }
+    }
+    std::mutex mu_, run_mu_;
+    std::condition_variable cv_work_, cv_done_;
+    const std::function<void(int)>* job_ = nullptr;
+    int n_chunks_ = 0, next_ = 0, done_ = 0, limit_ = 0, active_ = 0;
+    size_t n_workers_ = 0;
+};
+
 extern "C" int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, const int32_t* idx_rows, int n,
                                  void* dgesdd_ilp64, int threads, float* out_h) {
     if (!pts_a || !pts_b || !idx_rows || !out_h || !dgesdd_ilp64 || m <= 0 || n < 0) return RWH_E_INVALID;
@@ -54,19 +112,23 @@ extern "C" int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, 
         if (idx_rows[i] < 0 || idx_rows[i] >= m) return RWH_E_INVALID;
     if (n == 0) return RWH_OK;
     dgesdd_t f = reinterpret_cast<dgesdd_t>(dgesdd_ilp64);
-    int nt = threads < 1 ? 1 : threads;
-    if (nt > (n + 11) / 12) nt = (n + 11) / 12;            // a thread is worth starting for a dozen samples (~0.1 ms of LAPACK)
-    int bad = 0;
-    if (nt <= 1) {
+    int nt = threads < 1 ? 1 : (threads > 64 ? 64 : threads);
+    // samples per hand-out: ~50 us of LAPACK for small batches, larger pieces (fewer trips through the pool's mutex) for big ones
+    int CHUNK = n / (8 * nt);
+    CHUNK = CHUNK < 6 ? 6 : (CHUNK > 64 ? 64 : CHUNK);
+    const int n_chunks = (n + CHUNK - 1) / CHUNK;
+    if (nt <= 1 || n_chunks <= 1) {
+        int bad = 0;
         solve_range(f, pts_a, pts_b, idx_rows, 0, n, out_h, &bad);
-    } else {
-        std::vector<std::thread> pool;
-        std::vector<int> bads((size_t)nt, 0);
-        for (int w = 1; w < nt; ++w)
-            pool.emplace_back(solve_range, f, pts_a, pts_b, idx_rows, (int)((long long)n * w / nt), (int)((long long)n * (w + 1) / nt), out_h, &bads[(size_t)w]);
-        solve_range(f, pts_a, pts_b, idx_rows, 0, (int)((long long)n / nt), out_h, &bads[0]);
-        for (auto& th : pool) th.join();
-        for (int b : bads) bad |= b;
+        return bad ? RWH_E_LAUNCH : RWH_OK;
     }
+    std::vector<int> bads((size_t)n_chunks, 0);
+    const std::function<void(int)> job = [&](int c) {
+        const int b = c * CHUNK, e = b + CHUNK < n ? b + CHUNK : n;
+        solve_range(f, pts_a, pts_b, idx_rows, b, e, out_h, &bads[(size_t)c]);
+    };
+    HostPool::get().run(n_chunks, nt, job);
+    int bad = 0;
+    for (int b : bads) bad |= b;
     return bad ? RWH_E_LAUNCH : RWH_OK;
 }

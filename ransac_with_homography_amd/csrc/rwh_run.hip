@@ -1,0 +1,188 @@
+// rwh_ransac_run: the host driver of RANSAC.run (ransac.py:159-213 without the final refit) in native code.
+//
+// What the reference does per call is a Python loop over k samples; what this library does is ONE search on the GPU
+// (rwh_ransac_search: K1 + K2 + argmax) plus the "settle" step that makes the result exact with respect to the reference's
+// solver: every sample K1 flags (repeated index, non-finite, ill-conditioned) and every hypothesis whose count is within a
+// margin of a decision gets the reference's own H -- LAPACK dgesdd, rwh_host_dlt4_svd -- and is re-scored by K2; then the
+// accept rules (first count >= need wins and stops, else the first maximum) are applied.  Rounds 2-3 drove this from
+// Python (ransac._settle_on_host: still there for the batched and sharded forms, and as this function's twin in the CPU
+// tests); here the same logic runs without the interpreter between its ~30 small steps: one upload, the repeated-index
+// samples solved on host threads WHILE the GPU searches, one readback, usually one more solve / score / readback round.
+//
+// Buffers are the caller's (the function allocates nothing persistent): a device workspace and a page-locked host
+// workspace, laid out by rwh_ransac_run_layout.  The function synchronises the stream (its results are host values).
+#include <algorithm>
+#include <climits>
+#include <cstring>
+#include <vector>
+#include "rwh_common.h"
+
+namespace {
+// sections of the two workspaces (byte offsets, 256-byte aligned)
+enum { D_PA, D_PB, D_IDX, D_H, D_COUNTS, D_FLAGS, D_MASKS, D_BEST, D_HSET, D_CNTSET, D_MASKSET, D_END,
+       H_UP, H_COUNTS, H_FLAGS, H_CNTSET, H_HSET, H_MASK, H_ROWS, H_END, N_OFF };
+
+inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+void layout(int m, int k, long long* off) {
+    const size_t words = (size_t)(m + 63) / 64, K = (size_t)(k > 0 ? k : 1), M = (size_t)m;
+    size_t d = 0;
+    off[D_PA] = (long long)d; d += 8 * M;                 // pts_a, pts_b, idx: ONE contiguous upload (8-byte / 16-byte aligned pieces)
+    off[D_PB] = (long long)d; d += 8 * M;
+    d = (d + 15) & ~(size_t)15;
+    off[D_IDX] = (long long)d; d = up256(d + 16 * K);
+    off[D_H] = (long long)d; d = up256(d + 36 * K);
+    off[D_COUNTS] = (long long)d; d += 4 * K;             // counts then flags: ONE contiguous readback
+    off[D_FLAGS] = (long long)d; d = up256(d + K);
+    off[D_MASKS] = (long long)d; d = up256(d + 8 * words * K);
+    off[D_BEST] = (long long)d; d = up256(d + 64);
+    off[D_HSET] = (long long)d; d = up256(d + 36 * K);
+    off[D_CNTSET] = (long long)d; d = up256(d + 4 * K);
+    off[D_MASKSET] = (long long)d; d = up256(d + 8 * words * K);
+    off[D_END] = (long long)d;
+    size_t h = 0;
+    off[H_UP] = (long long)h; h = up256(h + (size_t)(off[D_IDX] - off[D_PA]) + 16 * K);
+    off[H_COUNTS] = (long long)h; h += 4 * K;
+    off[H_FLAGS] = (long long)h; h = up256(h + K);
+    off[H_CNTSET] = (long long)h; h = up256(h + 4 * K);
+    off[H_HSET] = (long long)h; h = up256(h + 36 * K);
+    off[H_MASK] = (long long)h; h = up256(h + 8 * words);
+    off[H_ROWS] = (long long)h; h = up256(h + 16 * K);
+    off[H_END] = (long long)h;
+}
+
+inline int margin_of(int best, int cap) { const int v = 3 + (best > 0 ? best : 0) / 16; return v < cap ? v : cap; }
+}  // namespace
+
+extern "C" int rwh_ransac_run_layout(int m, int k, long long* offsets, int n_offsets) {
+    if (!offsets || m <= 0 || k < 0 || n_offsets < N_OFF) return RWH_E_INVALID;
+    layout(m, k, offsets);
+    return N_OFF;
+}
+
+extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const int32_t* idx, int k, double th, int loss,
+                              int need, int margin_cap, void* dgesdd_ilp64, int threads, void* d_ws, void* h_ws,
+                              int32_t* out, uint64_t* out_mask, void* stream) {
+    if (!pts_a || !pts_b || !idx || !d_ws || !h_ws || !out || !out_mask || !dgesdd_ilp64 || m <= 0 || k < 0) return RWH_E_INVALID;
+    if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ || margin_cap < 0) return RWH_E_INVALID;
+    for (long long i = 0; i < 4ll * k; ++i)
+        if (idx[i] < 0 || idx[i] >= m) return RWH_E_INVALID;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    long long off[N_OFF];
+    layout(m, k, off);
+    unsigned char* D = static_cast<unsigned char*>(d_ws);
+    unsigned char* Hh = static_cast<unsigned char*>(h_ws);
+    const int words = (m + 63) / 64;
+    float* d_pa = reinterpret_cast<float*>(D + off[D_PA]);
+    float* d_pb = reinterpret_cast<float*>(D + off[D_PB]);
+    int32_t* d_idx = reinterpret_cast<int32_t*>(D + off[D_IDX]);
+    float* d_H = reinterpret_cast<float*>(D + off[D_H]);
+    int32_t* d_counts = reinterpret_cast<int32_t*>(D + off[D_COUNTS]);
+    uint8_t* d_flags = D + off[D_FLAGS];
+    uint64_t* d_masks = reinterpret_cast<uint64_t*>(D + off[D_MASKS]);
+    uint64_t* d_best = reinterpret_cast<uint64_t*>(D + off[D_BEST]);
+    float* d_hset = reinterpret_cast<float*>(D + off[D_HSET]);
+    int32_t* d_cntset = reinterpret_cast<int32_t*>(D + off[D_CNTSET]);
+    uint64_t* d_maskset = reinterpret_cast<uint64_t*>(D + off[D_MASKSET]);
+    int32_t* h_counts = reinterpret_cast<int32_t*>(Hh + off[H_COUNTS]);
+    uint8_t* h_flags = Hh + off[H_FLAGS];
+    int32_t* h_cntset = reinterpret_cast<int32_t*>(Hh + off[H_CNTSET]);
+    float* h_hset = reinterpret_cast<float*>(Hh + off[H_HSET]);
+    uint64_t* h_mask = reinterpret_cast<uint64_t*>(Hh + off[H_MASK]);
+    int32_t* h_rows = reinterpret_cast<int32_t*>(Hh + off[H_ROWS]);
+
+    for (int i = 0; i < 6; ++i) out[i] = 0;
+    out[0] = -1;
+    for (int w = 0; w < words; ++w) out_mask[w] = 0;
+    if (k == 0) return RWH_OK;
+
+    // ---- one upload: correspondences + index table; the search goes out behind it ---------------------------------------
+    const size_t up_bytes = (size_t)(off[D_IDX] - off[D_PA]) + 16 * (size_t)k;
+    unsigned char* up = Hh + off[H_UP];
+    memcpy(up + (off[D_PA] - off[D_PA]), pts_a, 8 * (size_t)m);
+    memcpy(up + (off[D_PB] - off[D_PA]), pts_b, 8 * (size_t)m);
+    memcpy(up + (off[D_IDX] - off[D_PA]), idx, 16 * (size_t)k);
+    if (hipMemcpyAsync(D + off[D_PA], up, up_bytes, hipMemcpyHostToDevice, s) != hipSuccess) return RWH_E_LAUNCH;
+    int st = rwh_ransac_search(d_pa, d_pb, m, d_idx, k, th, loss, need, 0, d_H, d_flags, d_counts, d_masks, d_best, 1, s);
+    if (st != RWH_OK) return st;
+    if (hipMemcpyAsync(h_counts, d_counts, 5 * (size_t)k, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;   // counts + flags
+
+    // ---- hypotheses settled so far: position in the Hset / cnt_set / mask_set tables, -1 = not settled -------------------
+    std::vector<int> pos((size_t)k, -1), cnt((size_t)k, 0);
+    int nset = 0, rounds = 0;
+    auto settle = [&](int n_rows) -> int {      // h_rows[0..n_rows) -> H by the reference's solver, counts + masks by K2
+        if (n_rows == 0) return RWH_OK;
+        std::vector<int32_t> samples(4 * (size_t)n_rows);
+        for (int j = 0; j < n_rows; ++j) memcpy(&samples[4 * (size_t)j], idx + 4 * (size_t)h_rows[j], 16);
+        int r = rwh_host_dlt4_svd(pts_a, pts_b, m, samples.data(), n_rows, dgesdd_ilp64, threads, h_hset + 9 * (size_t)nset);
+        if (r != RWH_OK) return r;
+        if (hipMemcpyAsync(d_hset + 9 * (size_t)nset, h_hset + 9 * (size_t)nset, 36 * (size_t)n_rows, hipMemcpyHostToDevice, s) != hipSuccess) return RWH_E_LAUNCH;
+        r = rwh_score_count(d_hset + 9 * (size_t)nset, d_pa, d_pb, m, n_rows, th, loss, INT_MAX, 0, d_cntset + nset,
+                            d_maskset + (size_t)nset * words, d_best + 4, nullptr, s);
+        if (r != RWH_OK) return r;
+        if (hipMemcpyAsync(h_cntset + nset, d_cntset + nset, 4 * (size_t)n_rows, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;
+        return RWH_OK;
+    };
+    auto absorb = [&](int n_rows) {             // after the stream has been synchronised
+        for (int j = 0; j < n_rows; ++j) { pos[(size_t)h_rows[j]] = nset + j; cnt[(size_t)h_rows[j]] = h_cntset[nset + j]; }
+        nset += n_rows;
+    };
+
+    // ---- while the GPU searches: the samples the host already knows K1 will flag (a repeated index) -----------------------
+    int n_rep = 0;
+    for (int i = 0; i < k; ++i) {
+        const int32_t* q = idx + 4 * (size_t)i;
+        if ((q[0] == q[1]) | (q[0] == q[2]) | (q[0] == q[3]) | (q[1] == q[2]) | (q[1] == q[3]) | (q[2] == q[3])) h_rows[n_rep++] = i;
+    }
+    st = settle(n_rep);
+    if (st != RWH_OK) return st;
+    if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
+    for (int i = 0; i < k; ++i) cnt[(size_t)i] = h_counts[i];
+    absorb(n_rep);
+    int n_flagged = 0;
+    for (int i = 0; i < k; ++i) n_flagged += h_flags[i] != 0;
+
+    // ---- rounds: settle every hypothesis that can take part in the decision (ransac._settle_on_host, same rules) ----------
+    int end = k;
+    for (;;) {
+        end = k;
+        const int m_need = margin_of(need, margin_cap);
+        for (int i = 0; i < k; ++i) {
+            const bool sure = pos[(size_t)i] >= 0 ? cnt[(size_t)i] >= need : (h_flags[i] == 0 && cnt[(size_t)i] >= need + m_need);
+            if (sure) { end = i + 1; break; }
+        }
+        int best = 0;
+        for (int i = 0; i < end; ++i)
+            if ((pos[(size_t)i] >= 0 || h_flags[i] == 0) && cnt[(size_t)i] > best) best = cnt[(size_t)i];
+        const int m_best = margin_of(best, margin_cap);
+        int n_rows = 0;
+        for (int i = 0; i < end; ++i)
+            if (pos[(size_t)i] < 0 && (h_flags[i] != 0 || cnt[(size_t)i] >= best - m_best || cnt[(size_t)i] >= need - m_need)) h_rows[n_rows++] = i;
+        if (n_rows == 0) break;
+        ++rounds;
+        st = settle(n_rows);
+        if (st != RWH_OK) return st;
+        if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
+        absorb(n_rows);
+    }
+
+    // ---- the accept rules (ransac.py:186-202) over the prefix the reference looks at ------------------------------------
+    int winner = -1, early = 0;
+    for (int i = 0; i < end; ++i)
+        if (cnt[(size_t)i] >= need) { winner = i; early = 1; break; }
+    if (winner < 0) {
+        int bestc = 0;
+        for (int i = 0; i < end; ++i)
+            if (cnt[(size_t)i] > bestc) { bestc = cnt[(size_t)i]; winner = i; }       // strict >: the first index of the maximum
+    }
+    out[0] = winner; out[1] = early; out[2] = winner >= 0 ? cnt[(size_t)winner] : 0; out[3] = nset; out[4] = rounds; out[5] = n_flagged;
+    if (winner >= 0) {
+        const uint64_t* src = pos[(size_t)winner] >= 0 ? d_maskset + (size_t)pos[(size_t)winner] * words : d_masks + (size_t)winner * words;
+        if (hipMemcpyAsync(h_mask, src, 8 * (size_t)words, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;
+        if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
+        for (int w = 0; w < words; ++w) out_mask[w] = h_mask[w];
+    }
+    // for the caller's diagnostics: the settled counts replace K2's in the host copy (the device copy keeps K2's own)
+    for (int i = 0; i < k; ++i) h_cntset[i] = cnt[(size_t)i];      // (h_cntset is free again: every batch has been absorbed)
+    return RWH_OK;
+}

@@ -191,6 +191,79 @@ def ransac_search(pts_a, pts_b, idx, th, loss, need, ws, hyp_base=0, reset_best=
     return ws
 
 
+_pinned_run_ws = {}
+
+
+class RunWorkspace:
+    """Buffers of one `rwh_ransac_run` call: a device workspace (fresh per run: `RANSAC.last_run` keeps views into it) and a
+    page-locked host workspace (cached per (m, k): page-locking is the expensive part), laid out by rwh_ransac_run_layout."""
+    D_H, D_COUNTS, D_FLAGS, D_MASKS, D_END, H_COUNTS, H_FLAGS, H_CNTSET, H_END = 3, 4, 5, 6, 11, 13, 14, 15, 19
+
+    def __init__(self, m, k, device):
+        lib = _lib.load()
+        self.m, self.k, self.words = int(m), int(k), (int(m) + 63) // 64
+        off = (ctypes.c_longlong * 20)()
+        n = lib.rwh_ransac_run_layout(self.m, self.k, off, 20)
+        if n != 20:
+            check(n if n < 0 else _lib_invalid(), "rwh_ransac_run_layout")
+        self.off = list(off)
+        self.dev = torch.empty(self.off[self.D_END], dtype=torch.uint8, device=device)
+        key = (self.m, self.k)
+        if key not in _pinned_run_ws:
+            if len(_pinned_run_ws) > 8:
+                _pinned_run_ws.clear()
+            _pinned_run_ws[key] = torch.empty(self.off[self.H_END], dtype=torch.uint8, pin_memory=True)
+        self.host = _pinned_run_ws[key]
+
+    def _dview(self, which, nbytes, dtype):
+        return self.dev[self.off[which]:self.off[which] + nbytes].view(dtype)
+
+    @property
+    def H(self):
+        return self._dview(self.D_H, 36 * self.k, torch.float32).reshape(self.k, 9)
+
+    @property
+    def counts(self):
+        return self._dview(self.D_COUNTS, 4 * self.k, torch.int32)
+
+    @property
+    def flags(self):
+        return self._dview(self.D_FLAGS, self.k, torch.uint8)
+
+    @property
+    def masks(self):
+        return self._dview(self.D_MASKS, 8 * self.words * self.k, torch.int64).reshape(self.k, self.words)
+
+    def host_counts(self, settled=False):
+        """K2's raw counts (or, settled=True, the counts after the settle step) as a host int32 array (a copy)."""
+        o = self.off[self.H_CNTSET if settled else self.H_COUNTS]
+        return self.host[o:o + 4 * self.k].numpy().view(np.int32).copy()
+
+    def host_flags(self):
+        o = self.off[self.H_FLAGS]
+        return self.host[o:o + self.k].numpy().copy()
+
+
+def _lib_invalid():
+    return -1
+
+
+def ransac_run(pts_a, pts_b, idx, th, loss, need, margin_cap, ws, dgesdd, threads):
+    """rwh_ransac_run: upload + search + settle + accept rules in ONE native call.  pts_a / pts_b: float32 [M, 2] HOST arrays,
+    idx: int32 [K, 4] host array.  -> (winner | None, early, count, host_solved, rounds, flagged, mask_words uint64 [words])."""
+    lib = _lib.load()
+    assert pts_a.dtype == np.float32 and pts_b.dtype == np.float32 and idx.dtype == np.int32
+    assert pts_a.flags.c_contiguous and pts_b.flags.c_contiguous and idx.flags.c_contiguous
+    assert pts_a.shape == (ws.m, 2) and pts_b.shape == (ws.m, 2) and idx.shape == (ws.k, 4)
+    out = np.zeros(6, dtype=np.int32)
+    mask = np.zeros(ws.words, dtype=np.uint64)
+    check(lib.rwh_ransac_run(pts_a.ctypes.data, pts_b.ctypes.data, ws.m, idx.ctypes.data, ws.k, float(th), RWH_LOSS[loss], int(need),
+                             int(margin_cap), ctypes.c_void_p(dgesdd), int(threads), _ptr(ws.dev), ctypes.c_void_p(ws.host.data_ptr()),
+                             out.ctypes.data, mask.ctypes.data, _lib.stream_ptr()), "rwh_ransac_run")
+    winner = int(out[0])
+    return (winner if winner >= 0 else None), bool(out[1]), int(out[2]), int(out[3]), int(out[4]), int(out[5]), mask
+
+
 class BatchWorkspace:
     """Device buffers of one batched search: P problems x K hypotheses (rwh_ransac_batched)."""
 

@@ -21,13 +21,15 @@ generator exactly as k successive `np.random.randint(0, M, 4)` calls would
 
 Solver parity (ransac.py:177 draws WITH replacement; homography.py:81-87): a sample with a repeated
 index gives a rank-deficient 8 x 9 system, for which the reference still takes whatever null vector
-LAPACK's SVD returns and lets it compete for the running best; and on ill-conditioned samples K1's
-float64 elimination and LAPACK can round to neighbouring float32 H.  `_settle_on_host` therefore
-re-derives, with the reference's own arithmetic (float32 DLT matrix -> numpy.linalg.svd -> /h[8],
-the host branch of `calcHomography`), every hypothesis K1 flagged and every unflagged one whose
-count is within `RESCORE_MARGIN` of the best (or of the early-exit count), re-scores those rows with
-K2 (bit-exact given H) and only then applies the accept rules.  ~4 % of the samples at M = 185:
-about 40 SVDs (0.5 ms of host time) for k = 1000.
+LAPACK's SVD returns and lets it compete for the running best; an ill-conditioned sample (three collinear
+source points, equal coordinates at different indices) gives K1 and LAPACK unrelated H; and on ~2 % of
+ordinary samples the two round to neighbouring float32 H.  K1 flags the first two kinds
+(RWH_HYP_REPEATED / _SINGULAR / _ILLCOND) and `_settle_on_host` re-derives, with the reference's own
+arithmetic (float32 DLT matrix -> LAPACK dgesdd, the routine numpy.linalg.svd calls -> /h[8]: `svd_hypotheses`),
+every flagged hypothesis and every unflagged one whose count is within a margin of the best (or of the
+early-exit count), re-scores those rows with K2 (bit-exact given H) and only then applies the accept rules.
+The repeated-index samples are known before anything is launched: `presettle` solves them on the host
+while the GPU searches.  k = 1500 at M = 185: ~90 host solves in two batches, 0.8 ms per run end to end.
 
 There is no CPU implementation of the loop here: without librwh_hip.so and a GPU
 `RANSAC.run` raises `RwhUnavailable`.
@@ -84,6 +86,7 @@ def _points_rows(P):
 
 
 HOST_THREADS = max(1, min(16, (os.cpu_count() or 1)))
+FORCE_PYTHON_DRIVER = False        # tests: RANSAC.run through the Python twin of rwh_ransac_run
 
 
 def svd_hypotheses(pts_a, pts_b, idx_rows, threads=None):
@@ -361,26 +364,23 @@ class RANSAC(object):
         idx_host = np.random.randint(0, mx, (k, self.n))
 
         pa_host, pb_host = _points_rows(X), _points_rows(Y)
-        # one upload for the correspondences and the index table (three small copies cost ~20 us each)
         idx32 = np.ascontiguousarray(idx_host[:, :4], dtype=np.int32)
-        blob = torch.from_numpy(np.concatenate([pa_host.reshape(-1).view(np.uint8), pb_host.reshape(-1).view(np.uint8),
-                                                idx32.reshape(-1).view(np.uint8)])).to(dev)
-        nb = 8 * mx
-        pa = blob[:nb].view(torch.float32).reshape(mx, 2)
-        pb = blob[nb:2 * nb].view(torch.float32).reshape(mx, 2)
-        idx = blob[2 * nb:].view(torch.int32).reshape(k, 4)
-        ws = kernels.SearchWorkspace(k, mx, dev)
         need_i = kernels.need_count(mx, self.d, self.n)
         th = _weak_threshold(self.th)
-        kernels.ransac_search(pa, pb, idx, th, method, need_i, ws)             # enqueued; the host goes on
-        # while the GPU searches: the reference's solver for the samples the host already knows K1 will flag
-        pre = presettle(pa, pb, pa_host, pb_host, idx_host, np.flatnonzero(repeated_rows(idx_host)), th, method)
-        Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
-        counts_host, flags_host = ws.counts_flags()                           # one readback for counts + flags
-        stats = {"raw_counts": counts_host.copy()}           # K2 on K1's own H, before the settle step
-        winner, early, totalfit, mask_words, settled_rows, counts_host = _settle_on_host(
-            pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need_i, th, method,
-            self.rescore_margin, stats, pre=pre)
+        addr = _lapack.dgesdd_address()
+        if addr is not None and not FORCE_PYTHON_DRIVER:
+            # the whole driver in ONE native call (rwh_ransac_run, csrc/rwh_run.hip): upload, K1 + K2 + argmax, the settle step
+            # (repeated-index samples solved on host threads while the GPU searches), the accept rules
+            ws = kernels.RunWorkspace(mx, k, dev)
+            winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words = kernels.ransac_run(
+                pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS)
+            counts_host = ws.host_counts(settled=True)
+            stats = {"raw_counts": ws.host_counts(), "host_settled": n_set, "host_rounds": n_rounds, "flagged": n_flagged}
+            Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
+            settled_rows = _SettledRows(pa_host, pb_host, idx32)
+        else:
+            winner, early, totalfit, mask_words, settled_rows, counts_host, stats, (Hs, flags, counts, masks) = self._run_python_driver(
+                pa_host, pb_host, idx_host, idx32, k, mx, need_i, th, method, dev)
 
         if early:  # leave the generator where the reference's `break` would
             np.random.set_state(rng_state)
@@ -393,7 +393,7 @@ class RANSAC(object):
             inliers = (np.array([], dtype=np.int64),)
             totalfit = 0
         else:
-            words = mask_words if mask_words is not None else masks[winner].cpu().numpy()
+            words = mask_words
             bits = np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:mx]
             inliers = (np.nonzero(bits)[0].astype(np.int64),)
             totalfit = np.int64(totalfit)
@@ -405,6 +405,44 @@ class RANSAC(object):
         finalModel = self.model.fit(inliers_x, inliers_y, collective=True)
         self.model.val = finalModel
         return finalModel, inliers, totalfit
+
+
+    def _run_python_driver(self, pa_host, pb_host, idx_host, idx32, k, mx, need_i, th, method, dev):
+        """The same driver step by step from Python (rounds 2-3; used when numpy's LAPACK cannot be taken by address, and by
+        tests that compare the two drivers): one upload, rwh_ransac_search, `presettle` while the GPU searches, one readback,
+        `_settle_on_host`."""
+        import torch
+        if k == 0:      # no iteration: the reference keeps no model and its refit fails (ransac.py:206-208)
+            e = torch.empty(0, dtype=torch.int32, device=dev)
+            return None, False, 0, None, {}, np.zeros(0, np.int32), {"raw_counts": np.zeros(0, np.int32), "host_settled": 0, "host_rounds": 0,
+                                                                     "flagged": 0}, (e, e.to(torch.uint8), e, e)
+        blob = torch.from_numpy(np.concatenate([pa_host.reshape(-1).view(np.uint8), pb_host.reshape(-1).view(np.uint8),
+                                                idx32.reshape(-1).view(np.uint8)])).to(dev)
+        nb = 8 * mx
+        pa = blob[:nb].view(torch.float32).reshape(mx, 2)
+        pb = blob[nb:2 * nb].view(torch.float32).reshape(mx, 2)
+        idx = blob[2 * nb:].view(torch.int32).reshape(k, 4)
+        ws = kernels.SearchWorkspace(k, mx, dev)
+        kernels.ransac_search(pa, pb, idx, th, method, need_i, ws)             # enqueued; the host goes on
+        pre = presettle(pa, pb, pa_host, pb_host, idx_host, np.flatnonzero(repeated_rows(idx_host)), th, method)
+        counts_host, flags_host = ws.counts_flags()                           # one readback for counts + flags
+        stats = {"raw_counts": counts_host.copy()}           # K2 on K1's own H, before the settle step
+        winner, early, totalfit, mask_words, settled_rows, counts_host = _settle_on_host(
+            pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need_i, th, method, self.rescore_margin, stats, pre=pre)
+        if winner is not None and mask_words is None:
+            mask_words = ws.masks[winner].cpu().numpy()
+        return winner, early, totalfit, mask_words, settled_rows, counts_host, stats, (ws.H, ws.flags, ws.counts, ws.masks)
+
+
+class _SettledRows(object):
+    """`RANSAC.last_run["settled"]` of the native driver: index -> the H the settle step gives that hypothesis, i.e. the
+    reference's own (host SVD), computed on demand."""
+
+    def __init__(self, pa, pb, idx32):
+        self._pa, self._pb, self._idx = pa, pb, idx32
+
+    def __getitem__(self, i):
+        return svd_hypotheses(self._pa, self._pb, self._idx[int(i):int(i) + 1])[0]
 
 
 class DeviceProblems(object):

@@ -53,6 +53,35 @@ def test_argument_validation_without_gpu(lib):
     assert st == 0
 
 
+def test_round3_host_entry_points_without_gpu(lib):
+    """rwh_ransac_run_layout (pure arithmetic), argument validation of rwh_ransac_run / rwh_host_dlt4_svd / rwh_lab_clock_probe,
+    and the host solver itself -- rwh_host_dlt4_svd needs no GPU: it must reproduce the reference's H on golden samples."""
+    from ransac_with_homography_amd import _lapack
+    off = (ctypes.c_longlong * 20)()
+    assert lib.rwh_ransac_run_layout(185, 1500, off, 20) == 20
+    o = list(off)
+    assert o[0] == 0 and all(b >= a for a, b in zip(o[:12], o[1:12])) and all(b >= a for a, b in zip(o[12:19], o[13:20]))
+    assert o[5] == o[4] + 4 * 1500 and o[14] == o[13] + 4 * 1500            # counts and flags adjacent: one readback
+    assert o[11] > 36 * 1500 * 2 and o[19] > 16 * 1500
+    assert lib.rwh_ransac_run_layout(185, 1500, off, 19) == -1 and lib.rwh_ransac_run_layout(0, 10, off, 20) == -1
+    null = ctypes.c_void_p(0)
+    assert lib.rwh_ransac_run(null, null, 185, null, 10, 5.0, 0, 100, 8, null, 1, null, null, null, null, null) == -1
+    assert lib.rwh_host_dlt4_svd(null, null, 185, null, 4, null, 1, null) == -1
+    assert lib.rwh_lab_clock_probe(null, 1.0, null) == -1
+    addr = _lapack.dgesdd_address()
+    if addr is None:
+        pytest.skip("numpy's LAPACK symbol not found in this environment")
+    g = np.load(os.path.join(ROOT, "tests", "golden", "g2_hyp_seed0.npz"))
+    z = np.load(os.path.join(ROOT, "tests", "golden", "matchespoints.npz"))
+    pa, pb = np.ascontiguousarray(z["ptsA"]), np.ascontiguousarray(z["ptsB"])
+    idx = np.ascontiguousarray(g["idx"][:500], dtype=np.int32)
+    out = np.empty((500, 9), np.float32)
+    assert lib.rwh_host_dlt4_svd(pa.ctypes.data, pb.ctypes.data, 185, idx.ctypes.data, 500, ctypes.c_void_p(addr), 3, out.ctypes.data) == 0
+    assert np.array_equal(out.view(np.uint32), g["H"][:500].view(np.uint32))
+    bad = idx.copy(); bad[7, 2] = 185                                              # an index past the table: refused, nothing read
+    assert lib.rwh_host_dlt4_svd(pa.ctypes.data, pb.ctypes.data, 185, bad.ctypes.data, 500, ctypes.c_void_p(addr), 3, out.ctypes.data) == -1
+
+
 def test_new_entry_points_validate_and_plan(lib):
     """Round-2 entry points: NULL / bad arguments are refused before any device access, and rwh_warp_plan (the dispatch of
     rwh_warp_backward without the launch) names the kernel each configuration gets -- no GPU needed."""

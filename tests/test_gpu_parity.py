@@ -1650,3 +1650,38 @@ def test_ransac_run_random_problem_families_vs_oracle(gpu):
             assert isinstance(res[0], str) and isinstance(res[1], str), (case, res)
         else:
             assert res[0] == res[1], (case, kind, M, th, d, k, n, m, seed, res[0][:2], res[1][:2])
+
+
+def test_native_and_python_run_drivers_agree(gpu, matches):
+    """rwh_ransac_run (the native driver RANSAC.run uses) against its Python twin (`RANSAC._run_python_driver`: the same upload /
+    search / presettle / settle sequence step by step): identical winner, early flag, count, inlier list, settle statistics and
+    generator position on reference fixtures of every kind -- ordinary runs, low-inlier runs won by a repeated-index sample,
+    lattice / cluster problems, early exits, n = 6, k = 0."""
+    import contextlib
+    import io
+    import ransac as rs
+    from ransac_with_homography_amd import ransac as rmod
+    ptsA, ptsB = matches
+    g9, g12 = load_golden("g9_low_inlier"), load_golden("g12_illcond")
+    cases = [(ptsA, ptsB, 0, 5, 70, 4, 1000, "fwd"), (ptsA, ptsB, 1, 5, 50, 4, 1000, "reproj"), (ptsA, ptsB, 3, 5, 50, 6, 1000, "fwd"),
+             (ptsA, g9["ptsB_a"], 2, 5, 20, 4, 1000, "fwd"), (ptsA, g9["ptsB_b"], 2, 5, 70, 4, 1000, "backward"),
+             (g12["ptsA_lat2024"], g12["ptsB_lat2024"], 41, 3, 95, 4, 1500, "fwd"), (g12["ptsA_clus1"], g12["ptsB_clus1"], 3, 1, 101, 4, 1000, "fwd"),
+             (g12["ptsA_lat5"], g12["ptsB_lat5"], 3, 3, 70, 4, 1000, "reproj"), (ptsA, ptsB, 5, 5, 70, 4, 0, "fwd")]
+    for A, B, seed, th, d, n, k, m in cases:
+        res = []
+        for force in (False, True):
+            rmod.FORCE_PYTHON_DRIVER = force
+            try:
+                np.random.seed(seed)
+                r = rs.RANSAC(rs.HomoModel(th=th, d=d, n=n), k=k)
+                with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                    try:
+                        H, inl, cnt = r.run([A.T, B.T], method=m)
+                        res.append((r.last_run["winner"], r.last_run["early_exit"], int(cnt), inl[0].tolist(), r.last_run["host_settled"],
+                                    r.last_run["host_rounds"], r.last_run["flagged"], r.last_run["raw_counts"].tolist(),
+                                    r.last_run["flags"].cpu().numpy().tolist(), int(np.random.randint(0, 1 << 30)), np.asarray(H).tolist()))
+                    except AssertionError:
+                        res.append("AssertionError")        # k = 0: nothing to refit, like the reference
+            finally:
+                rmod.FORCE_PYTHON_DRIVER = False
+        assert res[0] == res[1], (seed, th, d, n, k, m, res[0][:7] if not isinstance(res[0], str) else res[0], res[1][:7] if not isinstance(res[1], str) else res[1])
