@@ -2,7 +2,8 @@
 import os, sys, numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from ransac_with_homography_amd import kernels
+from ransac_with_homography_amd import _lib, kernels
+if os.environ.get("RWH_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["RWH_LIB"])      # a lab build (tools/build_variant.sh)
 from ransac_with_homography_amd.homography import _bounds
 dev = torch.device("cuda")
 H = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
@@ -22,4 +23,6 @@ for dt, esz in ((torch.uint8, 1), (torch.float32, 4)):
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 50
     byt = B * (3 * SH * SW + 3 * oh * ow * esz)
+    import hashlib
+    print("sha1 %s  " % hashlib.sha1(dst.cpu().numpy().tobytes()).hexdigest()[:12], end="")
     print("%s out: %.3f ms per %d frames = %.2f us/frame, %.0f GB/s algorithmic = %.3f of 8 TB/s" % (str(dt), ms, B, ms * 1e3 / B, byt / ms / 1e6, byt / ms / 1e6 / 8000))
