@@ -52,8 +52,8 @@ RWH_API int rwh_abi_version(void);
 RWH_API const char* rwh_strerror(int code);
 
 /*
- * Lab / test hook, not part of the data path: pins a launch heuristic process-wide (value 0 = back to the library's
- * own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
+ * Lab / TEST-ONLY hook, not part of the data path and not thread-safe (plain process-wide globals): pins a launch heuristic
+ * (value 0 = back to the library's own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
  * hypotheses per wavefront of the scorer (1..64); RWH_TUNE_SCORE_EXACT: 1 = the scorer skips its reciprocal-based
  * filter and runs the two IEEE divisions for every pair (the filter only ever decides pairs that clear the threshold
  * by a proven error band, so counts and masks are the same either way).  Results never depend on any of them
@@ -304,7 +304,8 @@ RWH_API int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const 
  * Any other value: RWH_E_INVALID.
  * flags: RWH_WARP_ZERO_ORIGIN blanks texel (0,0) of imgT first, as bilinear() does to the caller's array;
  * RWH_STITCH_FAST: the staged float32-blend warp kernel with the compositor as its epilogue (rwh::warp_rgb8_comp) instead of
- * the float64 one-pixel-per-thread kernel: ~4x faster, canvas within 1 LSB of the reference's (the alpha plane's own
+ * the exact float64 kernel (four pixels per lane; 0.24 ms paste / 0.57 ms blend for a 13 181 x 6 313 canvas): 1.5-2.6x faster, canvas
+ * within 1 LSB of the reference's (the alpha plane's own
  * bilinear lerp is taken as constant: the one output pixel whose taps include the blanked texel (0,0) can differ more).
  */
 #define RWH_STITCH_FAST 4u
