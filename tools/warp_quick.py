@@ -41,8 +41,6 @@ for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
     same = "" if ref is None else (" identical to first kind: %s" % bool(torch.equal(ref, out)))
     if ref is None: ref = out.clone()
     import hashlib
-    digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12] if os.environ.get("SHA") else ""
-    import hashlib
     digest = hashlib.sha1(out.cpu().numpy().tobytes()).hexdigest()[:12] if os.environ.get("SHA") else ""      # SHA=1: digest of the output
     plan = kernels.warp_plan((frames, Hh, W, 3), torch.uint8, inv, grid, (Hh, W), "bilinear", torch.uint8)
     watts = ""
