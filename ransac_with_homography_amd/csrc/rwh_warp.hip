@@ -405,8 +405,15 @@ __global__ void zero_origin_kernel(unsigned char* src, long long stride, int bat
 // rwh_lab_tune(RWH_TUNE_WARP_SHAPE, 5|6|7) overrides (tests, lab).
 // (r0, c0, nr, nc): the part of the output grid the samples are taken from (the compositor's canvas extends past the warped
 // image's rectangle, where the map means nothing); default: the whole grid.
-static int choose_shape(const FastArgs& a, int r0 = 0, int c0 = 0, int nr = -1, int nc = -1) {
-    if (g_force_warp_shape) return g_force_warp_shape;
+// allow_halves (uint8 bilinear RGB, one homography): when no whole patch fits -- minification beyond ~1.28x -- the HALVES
+// form of the kernel is tried, 64 x 8 first (halves of 32 x 8: up to ~1.6x), then 32 x 16 (halves of 16 x 16: windows up
+// to ~2.2x); the return value is then the shape + 8.  Staging pays while a half's window holds at most HALVES_MAX_TEXELS
+// texels per output pixel: the gathers cost the same per output pixel whatever the minification s, the staged texels grow
+// as s^2 -- measured on 4K frames (profiles/r03_lab_notes.txt section 11): 1.4x 0.45 of the roofline staged vs 0.37
+// gathered, 1.5x 0.45 vs 0.38, 1.7x 0.44 vs 0.44, 2x 0.46 vs 0.59.
+constexpr double HALVES_MAX_TEXELS = 4.0;
+static int choose_shape(const FastArgs& a, int r0 = 0, int c0 = 0, int nr = -1, int nc = -1, bool allow_halves = false) {
+    if (g_force_warp_shape) return (g_force_warp_shape & 8) && !allow_halves ? 7 : g_force_warp_shape;
     if (nr < 0) { nr = a.out_h; nc = a.out_w; }
     int best = 0;
     double best_lines = 1e300;
@@ -426,7 +433,26 @@ static int choose_shape(const FastArgs& a, int r0 = 0, int c0 = 0, int nr = -1, 
         if (10 * fit < 9 * seen) continue;
         if (!best || lines_sum < 0.85 * best_lines) { best = lp; best_lines = lines_sum; }
     }
-    return best ? best : 7;   // nothing fits (strong zoom-out): every wave gathers; 128 x 4 has the longest stores
+    if (best) return best;
+    if (allow_halves) {
+        const int horder[2] = {6, 5};
+        for (int lp : horder) {
+            const int pw = 1 << lp, ph = 512 >> lp;
+            int seen = 0, fit = 0;
+            double staged = 0;
+            for (int i = 0; i < 5; ++i)
+                for (int j = 0; j < 5; ++j)
+                    for (int h = 0; h < 2; ++h) {
+                        const double r = r0 + (nr > ph ? (nr - ph) * (i / 4.0) : 0.0), c = c0 + (nc > pw ? (nc - pw) * (j / 4.0) : 0.0);
+                        long long fr, ft; double ln;
+                        if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c) + h * (pw / 2), pw / 2, ph, &fr, &ft, &ln)) continue;
+                        ++seen; fit += f8_window_fits(lp, fr, ft + 3);      // + 3: the window starts on a multiple of 4 texels
+                        staged += (double)fr * (double)(((ft + 6) >> 2) << 2);
+                    }
+            if (seen && 10 * fit >= 9 * seen && staged <= HALVES_MAX_TEXELS * 256.0 * seen) return lp + 8;
+        }
+    }
+    return 7;   // nothing fits (strong zoom-out): every wave gathers; 128 x 4 has the longest stores
 }
 
 // Coefficients of one homography on one output grid: X = cx[0] + row*cx[1] + col*cx[2] etc.
@@ -475,11 +501,14 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     if (px8) {
         for (int i = 0; i < n_h; ++i) {
             fill_coef(a.c, ih + 9 * i, x0, step_x, y0, step_y);
-            shape = comp ? choose_shape(a, comp->tsy, comp->tsx, comp->ht, comp->wt) : choose_shape(a);
+            const bool halves_ok = n_h == 1 && !comp && !nn && !custom && channels == 3 && dst_dtype == RWH_U8;
+            shape = comp ? choose_shape(a, comp->tsy, comp->tsx, comp->ht, comp->wt) : choose_shape(a, 0, 0, -1, -1, halves_ok);
             if (n_h > 1) { shape_of[i] = shape; shapes[shape - 5] = 1; }
         }
     }
     fill_coef(a.c, ih, x0, step_x, y0, step_y);
+    const bool halves = px8 && (shape & 8);
+    shape &= 7;
     const int pstr = (px8 && dst_dtype != RWH_U8) ? (1 << shape) / 8 : 1;
     if (px8) fill_offsets(a.c, shape, pstr);
     for (int j = 1; j <= 3; ++j) { a.dxs[j - 1][0] = j * a.c.cx[2]; a.dxs[j - 1][1] = j * a.c.cy[2]; a.dxs[j - 1][2] = j * a.c.cw[2]; }
@@ -506,6 +535,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         if (!kern) {
             if (nn) kern = shape == 7 ? warp_rgb8_nn<7> : shape == 6 ? warp_rgb8_nn<6> : warp_rgb8_nn<5>;
             else if (!px8) kern = u8 ? warp_rgb8_fast<unsigned char> : warp_rgb8_fast<float>;
+            else if (halves) kern = shape == 6 ? warp_rgb8_fast8h<6> : warp_rgb8_fast8h<5>;
             else if (shape == 7) kern = u8 ? warp_rgb8_fast8<unsigned char, 7> : warp_rgb8_fast8<float, 7>;
             else if (shape == 6) kern = u8 ? warp_rgb8_fast8<unsigned char, 6> : warp_rgb8_fast8<float, 6>;
             else kern = u8 ? warp_rgb8_fast8<unsigned char, 5> : warp_rgb8_fast8<float, 5>;
@@ -525,6 +555,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         }
         if (custom ? false : nn ? plan_only("rwh::warp_rgb8_nn<%.0s%d>", "", shape)
                           : !px8 ? plan_only("rwh::warp_rgb8_fast<%s>", u8 ? "unsigned char" : "float")
+                          : halves ? plan_only("rwh::warp_rgb8_fast8h<%.0s%d>", "", shape)
                                  : plan_only("rwh::warp_rgb8_fast8<%s, %d>", u8 ? "unsigned char" : "float", shape))
             return RWH_OK;
         hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a);

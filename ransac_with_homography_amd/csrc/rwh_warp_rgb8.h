@@ -643,9 +643,16 @@ template <typename DstT, int LOG_PW> constexpr int f8_waves() {
 // occupancy-sensitive (time ~ 9.5 + 35/n us per 4K frame for n resident waves per SIMD, n <= 5 measured) and this
 // keeps it at 6 waves (LDS-limited).  The end pixels are computed once, so the footprint and the taps can never
 // disagree about a floor().
-template <typename DstT, int LOG_PW, bool COMP = false, int CH = 3>
+//
+// HALVES (round 3, minification): a patch whose footprint does not fit the window is staged and blended ONE RUN AT A TIME --
+// the left half (every lane's run 0: PW/2 x PH pixels), then the right half, each with a window of its own in the same
+// slab.  A 16 x 16 half of a 32 x 16 patch fits the 40 x 38 window up to ~2.2x minification, where the whole patch stops
+// fitting at ~1.09x (64 x 8: 1.28x) and every wave used to gather.  The halves' corners are the run's own end pixels, so
+// footprint and taps agree about every floor() as they do for whole patches; a half that does not fit gathers.
+template <typename DstT, int LOG_PW, bool COMP = false, int CH = 3, bool HALVES = false>
 __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, const CompArgs* cp = nullptr) {
     static_assert(CH == 3 || (CH == 4 && !COMP && sizeof(DstT) == 1), "4 channels: uint8 RGBA in and out, no compositor");
+    static_assert(!HALVES || (!COMP && sizeof(DstT) == 1), "halves: uint8 output, no compositor");
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
     constexpr int LPR = PW / 8;                             // lanes per patch row
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
@@ -797,7 +804,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const int nrows = ymx - ymn + 2, C = (xmx - xmn + 5) >> 2;
     // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row (a chunk may read
     // up to 9 bytes past the footprint's last texel: never past the row below), and the footprint fits the window
-    const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
+    // (the HALVES kernel stages per half patch, below: no whole-patch window, no border window)
+    const bool staged = !HALVES & wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
                         (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
 
     // Border patches (4.8 % of a 4K frame's patches, 10.5 % of a 1080p frame's: some pixels map outside the source): the
@@ -806,7 +814,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     // windows that reach the last two source rows (a staging chunk may read 9 bytes past its last texel).
     int wxmn = xmn, wymn = ymn, wnrows = nrows, wC = C;
     bool border = false;
-    if (!staged & wpos) {
+    if (!HALVES & !staged & wpos) {
         const int cx0 = smin(smax(xmn, 0), a.bound_w - 1) & ~3, cx1 = smin(smax(xmx, 0), a.bound_w - 1);
         const int cy0 = smin(smax(ymn, 0), a.bound_h - 1), cy1 = smin(smax(ymx, 0), a.bound_h - 1);
         const int nr = smax(cy1 - cy0 + 2, Win::RPP), nc = (cx1 - cx0 + 5) >> 2;
@@ -1001,12 +1009,86 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         return;
     }
 
+    // ---- HALVES: one run at a time, each half patch with a window of its own; halves that do not fit are left to the gathers --
+    unsigned todo = 3u;                                         // uniform: runs still to do
+    if constexpr (HALVES) {
+        todo = wpos ? 0u : 3u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (!wpos) break;
+            run_coords(h);
+            {
+
+                const uint32_t lhx = h == 0 ? ehx[0] : hx[0], lhy = h == 0 ? ehy[0] : hy[0];      // the run's first pixel
+                const uint32_t rhx = h == 0 ? hx[3] : ehx[1], rhy = h == 0 ? hy[3] : ehy[1];      // ... and its last
+                const int hx0 = (int)__builtin_amdgcn_readlane(lhx, 0), hx1 = (int)__builtin_amdgcn_readlane(rhx, LPR - 1);
+                const int hx2 = (int)__builtin_amdgcn_readlane(lhx, 64 - LPR), hx3 = (int)__builtin_amdgcn_readlane(rhx, 63);
+                const int hy0 = (int)__builtin_amdgcn_readlane(lhy, 0), hy1 = (int)__builtin_amdgcn_readlane(rhy, LPR - 1);
+                const int hy2 = (int)__builtin_amdgcn_readlane(lhy, 64 - LPR), hy3 = (int)__builtin_amdgcn_readlane(rhy, 63);
+                const int qxmn = smin(smin(hx0, hx1), smin(hx2, hx3)) & ~3, qxmx = smax(smax(hx0, hx1), smax(hx2, hx3));
+                const int qymn = smin(smin(hy0, hy1), smin(hy2, hy3)), qymx = smax(smax(hy0, hy1), smax(hy2, hy3));
+                const int sxmn = (int)((uint32_t)qxmn - MAGIC_HI), sxmx = (int)((uint32_t)qxmx - MAGIC_HI);
+                const int symn = (int)((uint32_t)qymn - MAGIC_HI), symx = (int)((uint32_t)qymx - MAGIC_HI);
+                const int hrows = symx - symn + 2, hC = (sxmx - sxmn + 5) >> 2;
+                const bool hfits = (sxmn >= 0) & (sxmx < a.bound_w - 1) & (symn >= 0) & (symx < min(a.bound_h - 1, a.src_h - 2)) &
+                                   (hrows >= Win::RPP) & (hrows <= Win::ROWS) & (hC <= Win::LPRW);
+                if (hfits) {
+                    constexpr uint32_t lpitch = Win::LPITCH;
+                    const unsigned char* gbase = simg + (size_t)((uint32_t)symn * pitch + (uint32_t)sxmn * (uint32_t)CH);   // uniform
+                    const bool hactive = (srow < Win::RPP) & (scol < hC);
+                    chunk_t vh[Win::PASSES];
+#pragma unroll
+                    for (int p = 0; p < Win::PASSES; ++p)
+                        if (p * Win::RPP < hrows && hactive)
+                            __builtin_memcpy(&vh[p], gbase + (size_t)((uint32_t)min(p * Win::RPP, hrows - Win::RPP) * pitch) + goff, sizeof(chunk_t));
+#pragma unroll
+                    for (int p = 0; p < Win::PASSES; ++p)
+                        if (p * Win::RPP < hrows && hactive) {
+                            uint4 t4;
+                            if constexpr (CH == 4) {
+                                t4.x = vh[p].a; t4.y = vh[p].b; t4.z = vh[p].c; t4.w = vh[p].d;
+                            } else {
+                                t4.x = vh[p].a & 0xFFFFFFu;
+                                t4.y = __builtin_amdgcn_perm(vh[p].b, vh[p].a, 0x0C050403u);
+                                t4.z = __builtin_amdgcn_perm(vh[p].c, vh[p].b, 0x0C040302u);
+                                t4.w = vh[p].c >> 8;
+                            }
+                            *reinterpret_cast<uint4*>(my + (uint32_t)min(p * Win::RPP, hrows - Win::RPP) * lpitch + wl) = t4;
+                        }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    const uint32_t slab_off = (uint32_t)wave * (uint32_t)SLAB;
+                    const uint32_t tap_c = ((uint32_t)qymn & 0xFFFFFFu) * lpitch + ((uint32_t)qxmn << 2) - slab_off;   // uniform
+#pragma unroll
+                    for (int j = 0; j < FP_PX; ++j) {
+                        weights2(lx[j], ly[j], WS, WO, WC, wx0[j], wx1[j], wy0[j], wy1[j]);
+                        const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
+                        const uint32_t* t0 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo);
+                        const uint32_t* t1 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo + lpitch);
+                        a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
+                    }
+                    const int first = tshift - (lcol + (PW / 2) * h);
+                    blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
+                                                      store_any & (first <= 3 * PSTR), max(first, 0));
+                    // the slab is reused by the other half: this half's reads are complete (their values were consumed above)
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    continue;
+                }
+            }
+            todo |= 1u << h;
+        }
+        if (todo == 0u) return;
+    }
+
     // ---- everything else (windows that do not fit, the last two source rows, W <= 0): masked gathers from global memory --
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         uint32_t off[FP_PX];
         bool near_end = false;
         unsigned vbits = 0u;
+        if (HALVES && !(todo & (1u << h))) continue;
         run_coords(h);
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j) {
@@ -1053,6 +1135,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 
 template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
+// minification (see HALVES above): the same kernel, windows per half patch
+template <int LOG_PW>
+// (6 waves per SIMD for both shapes: at 7 the 64 x 8 form spills the destination pointer, and was 3 % slower in a same-box A/B)
+__global__ __launch_bounds__(256, 6) void warp_rgb8_fast8h(const FastArgs a) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, nullptr); }
 // RGBA uint8 in, RGBA uint8 out: 4-byte texels are slab texels as they lie in memory (no RGB -> RGBX expansion), a pixel is
 // one dword and a run one 16-byte store.  (The reference's own 4-channel images are float32: the generic kernel.)
 template <int LOG_PW>

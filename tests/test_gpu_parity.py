@@ -1218,6 +1218,51 @@ def test_warp_patch_shapes_vs_oracle(gpu, case, shape, monkeypatch):
     assert np.array_equal(part, u8[100:229])
 
 
+@pytest.mark.parametrize("case", ["zoom1p4", "zoom1p6", "zoom2", "zoom2_rot3", "persp_zoom", "zoom3"])
+def test_warp_minification_halves(gpu, case, monkeypatch):
+    """Minification: when no whole patch fits its staging window the host picks the kernel that stages a patch by halves
+    (rwh_warp_rgb8.h, HALVES).  Its arithmetic is the whole-patch kernel's, so the output must be BIT-IDENTICAL to the same
+    patch shape run with gathers (shapes 13 / 14 vs 5 / 6), whatever fits; and both are checked against the oracle."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(11)
+    sh, sw = 700, 1100
+    img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+
+    def zoom(s, deg=0.0):          # minification s about the image centre: output pixel spacing = s source texels
+        t = np.deg2rad(deg)
+        c, s_, cx, cy = np.cos(t) / s, np.sin(t) / s, sw / 2, sh / 2
+        return np.array([[c, -s_, cx - c * cx + s_ * cy], [s_, c, cy - s_ * cx - c * cy], [0, 0, 1.0]])
+    H = {"zoom1p4": zoom(1.4), "zoom1p6": zoom(1.6), "zoom2": zoom(2.0), "zoom2_rot3": zoom(1.9, 3.0), "zoom3": zoom(3.1),      # (exactly 3: a coordinate lands on the last column and the reference itself indexes out of bounds)
+         "persp_zoom": zoom(1.5) @ np.array([[1, 0.02, 0], [0.01, 1, 0], [2e-4, 1e-4, 1.0]])}[case]
+    inv = np.linalg.inv(H)
+    # the grid overhangs the warped image on every side (border patches, patches wholly outside) and is ragged
+    ow, oh = int(sw / 1.3) + 37, int(sh / 1.3) + 11
+    x0, y0 = sw / 2 - ow / 2 - 3.5, sh / 2 - oh / 2 + 2.25
+    xs, ys = np.linspace(x0, x0 + ow - 1, ow), np.linspace(y0, y0 + oh - 1, oh)
+    grid = kernels.Grid(xs[0], xs[-1], ow, ys[0], ys[-1], oh)
+    src = torch.from_numpy(img).to(gpu)
+    ref = _oracle_warp_on_grid(img, inv, xs, ys, (sh, sw))
+    outs = {}
+    for shape in (None, "5", "13", "6", "14"):
+        _force_shape(shape)
+        outs[shape] = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8)
+        plan = kernels.warp_plan((sh, sw, 3), torch.uint8, inv, grid, (sh, sw), "bilinear", torch.uint8)
+        if shape in ("13", "14"): assert "fast8h" in plan, plan
+        # the host's own choice: halves while staging pays (a window of <= 4 texels per output pixel), gathers beyond
+        if shape is None and case in ("zoom1p4", "zoom1p6"): assert "fast8h" in plan, plan
+        if shape is None and case in ("zoom2", "zoom3"): assert "fast8h" not in plan, plan
+    _force_shape(None)
+    assert torch.equal(outs["13"], outs["5"]) and torch.equal(outs["14"], outs["6"])
+    for shape, o in outs.items():
+        d = np.abs(o.cpu().numpy().astype(np.int16) - ref.astype(np.uint8).astype(np.int16))
+        # (an axis-aligned zoom by 1.4 / 1.6 / 2 puts the fractions on a lattice where many float64 blends are exact integers:
+        #  the float32 blend then lands a hair under some of them and truncates to one less -- 1 LSB, up to ~3 % of the bytes)
+        assert (d > 1).sum() <= 9 and (d != 0).mean() < 0.05, (case, shape, int((d > 1).sum()), float((d != 0).mean()))
+    # row shards agree bit for bit with the whole launch (the shape is a function of the whole grid)
+    part = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8, rows=(64, 203))
+    assert torch.equal(part, outs[None][64:203])
+
+
 def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
     """homography.py:166-179 with the nearest-neighbour interpolator on an arbitrary output grid."""
     from oracle import rwh_oracle as orc

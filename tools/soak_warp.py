@@ -18,6 +18,7 @@ for case in range(cases):
     if F32: img = img.float() * 0.37 + 0.11
     t = rng.uniform(-np.pi, np.pi) if case % 3 == 0 else rng.uniform(-0.08, 0.08)
     sx, sy = rng.uniform(0.5, 2.2, 2) if case % 5 == 0 else rng.uniform(0.85, 1.2, 2)
+    if os.environ.get("ZOOM"): sx, sy = 1.0 / rng.uniform(1.2, 2.4) * rng.uniform(0.95, 1.05, 2)      # ZOOM=1: minification (the HALVES kernel)
     A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.array([[sx, rng.uniform(-0.15, 0.15)], [0, sy]])
     H = np.eye(3); H[:2, :2] = A
     H[:2, 2] = rng.uniform(-60, 60, 2) + np.array([sw / 2, sh / 2]) - A @ np.array([sw / 2, sh / 2])
@@ -28,7 +29,7 @@ for case in range(cases):
     stepx, stepy = rng.uniform(0.8, 1.25, 2)
     grid = kernels.Grid(x0, x0 + stepx * (ow - 1), ow, y0, y0 + stepy * (oh - 1), oh)
     bound = (sh, sw) if case % 4 else (int(rng.integers(sh // 2, sh + 1)), int(rng.integers(sw // 2, sw + 1)))
-    shape = int(rng.choice([0, 0, 5, 6, 7]))
+    shape = int(rng.choice([0, 0, 5, 6, 7, 13, 14]))      # 13 / 14: staged by half patches (bilinear uint8 RGB; the other kernels then run 128 x 4)
     assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, shape) == 0
     ex = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.float64, zero_origin=False, exact=True)
     f32 = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.float32, zero_origin=False)

@@ -1,5 +1,5 @@
 """Developer probe: time the uint8 bilinear warp of the BASELINE workload per kernel kind (rwh_lab_tune).
-   python tools/warp_quick.py [kinds...]      kinds: 0 = the library's own choice, 5/6/7 = patch width 32/64/128 (default: 0 5 6 7)
+   python tools/warp_quick.py [kinds...]      kinds: 0 = the library's own choice, 5/6/7 = patch width 32/64/128, 13/14 = 32/64 staged by halves (default: 0 5 6 7)
    RWH_LIB=<path to another build of librwh_hip.so> (ablation builds), N=<timed launches>; prints the shader clock the
    chip held during the timed launches (rwh_lab_clock_probe)."""
 import os, sys
@@ -19,7 +19,8 @@ W, Hh = (int(v) for v in os.environ.get("SRC", "3840x2160").split("x"))
 dev = _lib.require_gpu()
 g = torch.Generator(device="cpu").manual_seed(1)
 src = torch.randint(0, 256, (frames, Hh, W, 3), dtype=torch.uint8, generator=g).to(dev)
-mx, my, ow, oh = (0, 0, W, Hh) if ("ROT" in os.environ or "SCALE" in os.environ) else hg._bounds(Hh, W, H_S, 0)
+# (rotation / zoom: the output grid is the source's own rectangle; BOUNDS=1: the warped image's bounding box, as the API takes it)
+mx, my, ow, oh = (0, 0, W, Hh) if (("ROT" in os.environ or "SCALE" in os.environ) and not os.environ.get("BOUNDS")) else hg._bounds(Hh, W, H_S, 0)
 ow = int(os.environ.get("OUTW", ow))          # OUTW=<n>: cut the output grid to n columns (store-alignment experiments)
 grid = kernels.Grid(mx, mx + ow - 1, ow, my, my + oh - 1, oh)
 inv = np.linalg.inv(H_S)
