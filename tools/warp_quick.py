@@ -19,6 +19,18 @@ W, Hh = (int(v) for v in os.environ.get("SRC", "3840x2160").split("x"))
 dev = _lib.require_gpu()
 g = torch.Generator(device="cpu").manual_seed(1)
 src = torch.randint(0, 256, (frames, Hh, W, 3), dtype=torch.uint8, generator=g).to(dev)
+if os.environ.get("DATA", "noise") != "noise":       # DATA=photo: smooth synthetic frames (low-frequency waves + +-3 of noise); DATA=zeros
+    # (a power-limited kernel's speed depends on how many bits toggle: uniform noise is the worst case, photographs are smooth)
+    if os.environ["DATA"] == "zeros": src.zero_()
+    else:
+        yy, xx = torch.meshgrid(torch.arange(Hh, device=dev, dtype=torch.float32), torch.arange(W, device=dev, dtype=torch.float32), indexing="ij")
+        for f in range(frames):
+            for c in range(3):
+                ph = 0.37 * f + 1.1 * c
+                img = 128 + 70 * torch.sin(xx * (0.004 + 0.0007 * c) + ph) * torch.cos(yy * (0.006 + 0.0005 * f / frames) - ph) + 35 * torch.sin((xx + yy) * 0.021 + ph)
+                img = img + torch.randint(-3, 4, (Hh, W), device=dev).float()
+                src[f, :, :, c] = img.clamp(0, 255).to(torch.uint8)
+        del yy, xx
 # (rotation / zoom: the output grid is the source's own rectangle; BOUNDS=1: the warped image's bounding box, as the API takes it)
 mx, my, ow, oh = (0, 0, W, Hh) if (("ROT" in os.environ or "SCALE" in os.environ) and not os.environ.get("BOUNDS")) else hg._bounds(Hh, W, H_S, 0)
 ow = int(os.environ.get("OUTW", ow))          # OUTW=<n>: cut the output grid to n columns (store-alignment experiments)
