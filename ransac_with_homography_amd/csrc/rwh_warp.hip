@@ -496,14 +496,16 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     a.gx0 = w.x0; a.gstep_x = w.step_x; a.gx_last = w.x_last; a.gy0 = w.y0; a.gstep_y = w.step_y; a.gy_last = w.y_last;
     a.out_h = w.out_h;
     // patch shape: the host's choice per homography; with one homography per image the images are grouped by shape
-    int shape = 0, shapes[3] = {0, 0, 0};
+    int shape = 0, shapes[16] = {};      // indexed by the shape code: 5..7, + 8 for the HALVES form
     std::vector<int> shape_of(n_h > 1 ? n_h : 0);
     if (px8) {
         for (int i = 0; i < n_h; ++i) {
             fill_coef(a.c, ih + 9 * i, x0, step_x, y0, step_y);
-            const bool halves_ok = n_h == 1 && !comp && !nn && !custom && channels == 3 && dst_dtype == RWH_U8;
+            // uint8 bilinear RGB only.  (RGBA was tried: its gathers are aligned 8-byte loads of exactly the two texels a tap
+            //  pair needs, and beat the halves at every minification -- 4K x 16, 1.4x: 0.57 of the roofline gathered vs 0.48 staged)
+            const bool halves_ok = !comp && !nn && !custom && channels == 3 && dst_dtype == RWH_U8;
             shape = comp ? choose_shape(a, comp->tsy, comp->tsx, comp->ht, comp->wt) : choose_shape(a, 0, 0, -1, -1, halves_ok);
-            if (n_h > 1) { shape_of[i] = shape; shapes[shape - 5] = 1; }
+            if (n_h > 1) { shape_of[i] = shape; shapes[shape] = 1; }
         }
     }
     fill_coef(a.c, ih, x0, step_x, y0, step_y);
@@ -562,18 +564,21 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         return check_launch();
     }
     // one homography per image: per shape, TAB_N images per launch with their coefficients as a second kernel argument
-    for (int sh = 7; sh >= 5; --sh) {
-        if (!shapes[sh - 5]) continue;
+    for (int code = 15; code >= 5; --code) {
+        if (!shapes[code]) continue;
+        const int sh = code & 7;
+        const bool hv = code & 8;            // images whose homography minifies: patches staged by halves
         const int ps = u8 ? 1 : (1 << sh) / 8;
         void (*kern)(const FastArgs, const CoefTab);
-        if (nn) kern = sh == 7 ? warp_rgb8_nn_tab<7> : sh == 6 ? warp_rgb8_nn_tab<6> : warp_rgb8_nn_tab<5>;
+        if (hv) kern = sh == 6 ? warp_rgb8_fast8h_tab<6> : warp_rgb8_fast8h_tab<5>;
+        else if (nn) kern = sh == 7 ? warp_rgb8_nn_tab<7> : sh == 6 ? warp_rgb8_nn_tab<6> : warp_rgb8_nn_tab<5>;
         else if (sh == 7) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 7> : warp_rgb8_fast8_tab<float, 7>;
         else if (sh == 6) kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 6> : warp_rgb8_fast8_tab<float, 6>;
         else kern = u8 ? warp_rgb8_fast8_tab<unsigned char, 5> : warp_rgb8_fast8_tab<float, 5>;
         CoefTab tab;
         int count = 0;
         for (int i = 0; i <= n_h; ++i) {
-            if (i < n_h && shape_of[i] == sh) {
+            if (i < n_h && shape_of[i] == code) {
                 fill_coef(tab.e[count], ih + 9 * i, x0, step_x, y0, step_y);
                 fill_offsets(tab.e[count], sh, ps);
                 tab.e[count++].image = i;
@@ -581,7 +586,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
             if (count == TAB_N || (i == n_h && count > 0)) {
                 for (int k = count; k < TAB_N; ++k) tab.e[k] = tab.e[0];
                 if (!geometry(count)) return RWH_E_UNSUPPORTED;
-                if (nn ? plan_only("rwh::warp_rgb8_nn_tab<%.0s%d>", "", sh) : plan_only("rwh::warp_rgb8_fast8_tab<%s, %d>", u8 ? "unsigned char" : "float", sh)) { count = 0; continue; }
+                if (hv ? plan_only("rwh::warp_rgb8_fast8h_tab<%.0s%d>", "", sh) : nn ? plan_only("rwh::warp_rgb8_nn_tab<%.0s%d>", "", sh) : plan_only("rwh::warp_rgb8_fast8_tab<%s, %d>", u8 ? "unsigned char" : "float", sh)) { count = 0; continue; }
                 hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a, tab);
                 if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
                 count = 0;

@@ -1139,6 +1139,8 @@ __global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fas
 template <int LOG_PW>
 // (6 waves per SIMD for both shapes: at 7 the 64 x 8 form spills the destination pointer, and was 3 % slower in a same-box A/B)
 __global__ __launch_bounds__(256, 6) void warp_rgb8_fast8h(const FastArgs a) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, nullptr); }
+template <int LOG_PW>
+__global__ __launch_bounds__(256, 6) void warp_rgb8_fast8h_tab(const FastArgs a, const CoefTab t) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, t.e); }
 // RGBA uint8 in, RGBA uint8 out: 4-byte texels are slab texels as they lie in memory (no RGB -> RGBX expansion), a pixel is
 // one dword and a run one 16-byte store.  (The reference's own 4-channel images are float32: the generic kernel.)
 template <int LOG_PW>

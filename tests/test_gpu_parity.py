@@ -1263,6 +1263,36 @@ def test_warp_minification_halves(gpu, case, monkeypatch):
     assert torch.equal(part, outs[None][64:203])
 
 
+def test_warp_minification_halves_per_image(gpu, monkeypatch):
+    """Batches with one homography per image: images whose homography minifies go to `warp_rgb8_fast8h_tab`, the others to
+    the whole-patch table kernel; every image equals its single-image launch bit for bit.  (uint8 RGBA keeps its gathers at
+    every minification -- they are faster there -- so its plan never names a halves kernel.)"""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(77)
+    sh, sw = 420, 900
+
+    def zoom(s, deg=0.0, px=0.0):
+        t = np.deg2rad(deg)
+        c, s_, cx, cy = np.cos(t) / s, np.sin(t) / s, sw / 2, sh / 2
+        return np.array([[c, -s_, cx - c * cx + s_ * cy], [s_, c, cy - s_ * cx - c * cy], [px, 0, 1.0]])
+    ow, oh = 701, 333
+    grid = kernels.Grid(90.5, 90.5 + ow - 1, ow, 40.25, 40.25 + oh - 1, oh)
+    assert "fast8h" not in kernels.warp_plan((sh, sw, 4), torch.uint8, np.linalg.inv(zoom(1.45, 1.0)), grid, (sh, sw), "bilinear", torch.uint8)
+    # one homography per image: minifying and non-minifying images in one call
+    n = 11
+    imgs = torch.from_numpy(rng.integers(0, 256, (n, sh, sw, 3), dtype=np.uint8)).to(gpu)
+    Hs = [zoom(1.5), zoom(1.0, 2.0), zoom(1.4, 8.0), zoom(1.7), zoom(2.6), zoom(1.0), zoom(1.55, 0.0, 1e-4), zoom(0.8), zoom(1.35, -3.0),
+          zoom(1.5), zoom(1.2, 30.0)]
+    invs = np.stack([np.linalg.inv(h) for h in Hs])
+    per = kernels.warp_backward(imgs, invs, grid, (sh, sw), "bilinear", torch.uint8)
+    plans = set()
+    for i in range(n):
+        one = kernels.warp_backward(imgs[i].contiguous(), invs[i], grid, (sh, sw), "bilinear", torch.uint8)
+        assert torch.equal(per[i], one), i
+        plans.add(kernels.warp_plan((sh, sw, 3), torch.uint8, invs[i], grid, (sh, sw), "bilinear", torch.uint8))
+    assert any("fast8h" in p for p in plans) and any("fast8<" in p for p in plans), plans
+
+
 def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
     """homography.py:166-179 with the nearest-neighbour interpolator on an arbitrary output grid."""
     from oracle import rwh_oracle as orc
