@@ -31,6 +31,43 @@ if len(sys.argv) > 3 and sys.argv[3] == "--blocks":
                   (name, n("v_"), n("s_"), n("ds_"), n("global_"), n("scratch_"), sum(v for k, v in c.items() if "cvt_f32_ubyte" in k),
                    sum(v for k, v in c.items() if "_u64" in k and k.startswith("v_cmp")), c.get("v_writelane_b32", 0)))
     sys.exit(0)
+if len(sys.argv) > 4 and sys.argv[3] == "--path":
+    # histogram of an explicit list of basic blocks (round 3: pick the staged path's blocks from the --blocks listing:
+    # the entry blocks, the staging-load and LDS-write blocks, the two run blocks with 8 LDS reads and no 64-bit compares)
+    want = set(sys.argv[4].split(","))
+    text = open(path).read()
+    a = text.index(sym + ":"); b = text.index(".Lfunc_end", a)
+    name, cur, blocks = "entry", [], {}
+    for l in text[a:b].split("\n"):
+        l = l.strip()
+        if not l or l.startswith(";"): continue
+        m = re.match(r"^\.LBB\d+_(\d+):", l)
+        if m: blocks[name] = cur; name, cur = m.group(1), []
+        else: cur.append(l)
+    blocks[name] = cur
+    tot = collections.Counter()
+    for n in want:
+        tot.update(m.group(0) for m in (re.match(r"^(v_|s_|ds_|global_)\S+", l) for l in blocks[n]) if m)
+    valu = sum(v for k, v in tot.items() if k.startswith("v_"))
+    print("blocks %s: VALU %d per wave = %.2f per pixel (8 px per lane); SALU %d; LDS %d; VMEM %d" %
+          (sys.argv[4], valu, valu / 8, sum(v for k, v in tot.items() if k.startswith("s_")),
+           sum(v for k, v in tot.items() if k.startswith("ds_")), sum(v for k, v in tot.items() if k.startswith("global_"))))
+    groups = [("blend (v_fma_mix_f32 on float16 tap halves)", r"v_fma_mix_f32"), ("tap halves (v_perm_b32) + RGB -> RGBX expansion", r"v_perm_b32|v_alignbyte"),
+              ("weights (v_cvt_f32_u32, v_pk_mul_f32, v_pk_fma_f32, v_pk_add_f32, v_mul_f32, v_fma_f32)", r"v_cvt_f32_u32|v_pk_mul_f32|v_pk_fma_f32|v_sub_f32|v_mul_f32|v_fma_f32|v_fmac_f32|v_pk_add_f32"),
+              ("convert + pack (v_cvt_pk_u8_f32, v_or3 / v_lshlrev / v_and of the 12-byte store words)", r"v_cvt_pk_u8_f32|v_or3_b32|v_and_or_b32"),
+              ("float64 coordinates (v_*_f64)", r"_f64"),
+              ("tap / staging addresses (24-bit multiplies, shifts, adds, min)", r"v_mul_u32_u24|v_mad_u32_u24|v_lshl_add_u32|v_lshlrev_b32|v_lshrrev_b32|v_add_u32|v_sub_u32|v_min_u32|v_min_i32|v_mul_lo_u32|v_mad_u64|v_lshl_add_u64|v_add3|v_mad_i32_i24|v_and_b32"),
+              ("cross-lane (v_readlane / readfirstlane)", r"v_readlane|v_readfirstlane")]
+    left = dict((k, v) for k, v in tot.items() if k.startswith("v_"))
+    for gname, rx in groups:
+        hit = [(k, v) for k, v in left.items() if re.search(rx, k)]
+        n = sum(v for _, v in hit)
+        for k, _ in hit: del left[k]
+        print("   %-100s %3d  = %5.2f per pixel   (%s)" % (gname, n, n / 8, ", ".join("%s %d" % kv for kv in sorted(hit, key=lambda kv: -kv[1]))))
+    n = sum(left.values())
+    print("   %-100s %3d  = %5.2f per pixel   (%s)" % ("other", n, n / 8, ", ".join("%s %d" % kv for kv in sorted(left.items(), key=lambda kv: -kv[1]))))
+    print("   memory: " + ", ".join("%s %d" % kv for kv in sorted(tot.items()) if kv[0].startswith(("ds_", "global_"))))
+    sys.exit(0)
 lines = open(path).read().split("\n")
 start = next(i for i, l in enumerate(lines) if l.startswith(sym + ":"))
 end = next(i for i in range(start, len(lines)) if lines[i].startswith(".Lfunc_end"))
