@@ -34,7 +34,8 @@ if len(sys.argv) > 3 and sys.argv[3] == "--blocks":
 if len(sys.argv) > 4 and sys.argv[3] == "--path":
     # histogram of an explicit list of basic blocks (round 3: pick the staged path's blocks from the --blocks listing:
     # the entry blocks, the staging-load and LDS-write blocks, the two run blocks with 8 LDS reads and no 64-bit compares)
-    want = set(sys.argv[4].split(","))
+    # "9:81" = block 9 up to its branch to block 81 (a labelled block may hold several branches; the code behind the taken one is not on the path)
+    want = [w.split(":") for w in sys.argv[4].split(",")]
     text = open(path).read()
     a = text.index(sym + ":"); b = text.index(".Lfunc_end", a)
     name, cur, blocks = "entry", [], {}
@@ -46,8 +47,12 @@ if len(sys.argv) > 4 and sys.argv[3] == "--path":
         else: cur.append(l)
     blocks[name] = cur
     tot = collections.Counter()
-    for n in want:
-        tot.update(m.group(0) for m in (re.match(r"^(v_|s_|ds_|global_)\S+", l) for l in blocks[n]) if m)
+    for w in want:
+        bl = blocks[w[0]]
+        if len(w) > 1:
+            cut = next(i for i, l in enumerate(bl) if re.match(r"^s_c?branch\S* \.LBB\d+_%s$" % w[1], l))
+            bl = bl[:cut + 1]
+        tot.update(m.group(0) for m in (re.match(r"^(v_|s_|ds_|global_)\S+", l) for l in bl) if m)
     valu = sum(v for k, v in tot.items() if k.startswith("v_"))
     print("blocks %s: VALU %d per wave = %.2f per pixel (8 px per lane); SALU %d; LDS %d; VMEM %d" %
           (sys.argv[4], valu, valu / 8, sum(v for k, v in tot.items() if k.startswith("s_")),
