@@ -53,7 +53,7 @@ RWH_API const char* rwh_strerror(int code);
 
 /*
  * Lab / TEST-ONLY hook, not part of the data path and not thread-safe (plain process-wide globals): pins a launch heuristic
- * (value 0 = back to the library's own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7); RWH_TUNE_SCORE_HPW:
+ * (value 0 = back to the library's own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7; 13, 14 = 32 x 16 / 64 x 8 patches staged by halves, the minification form of the uint8 RGB kernel); RWH_TUNE_SCORE_HPW:
  * hypotheses per wavefront of the scorer (1..64); RWH_TUNE_SCORE_EXACT: 1 = the scorer skips its reciprocal-based
  * filter and runs the two IEEE divisions for every pair (the filter only ever decides pairs that clear the threshold
  * by a proven error band, so counts and masks are the same either way).  Results never depend on any of them
