@@ -332,6 +332,34 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
     }
 }
 
+// A run of 4 pixels that all map outside the source: zeros, in blend_store's store layout (`shift` as there).
+template <typename DstT, int PSTR, int CH>
+__device__ __forceinline__ void zero_store(DstT* drow, bool store_any, int shift) {
+    if (!store_any) return;
+    if constexpr (PSTR > 1) {                                 // float32 output of the 8 px kernel: pixels PSTR columns apart
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j)
+            if (j * PSTR >= shift) { const pk3 z = {0u, 0u, 0u}; __builtin_memcpy(drow + 3 * j * PSTR, &z, 12); }
+    } else if (shift == 0) {
+        if constexpr (CH * sizeof(DstT) == 3) { const pk3 z = {0u, 0u, 0u}; __builtin_memcpy(drow, &z, 12); }
+        else if constexpr (CH * sizeof(DstT) == 4) {          // RGBA uint8: one aligned 16-byte store
+            uint32_t* d32 = reinterpret_cast<uint32_t*>(__builtin_assume_aligned(drow, 4));
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) d32[j] = 0u;
+        } else {
+#pragma unroll
+            for (int v = 0; v < 3; ++v) { const pk4 z = {0u, 0u, 0u, 0u}; __builtin_memcpy(reinterpret_cast<unsigned char*>(drow) + 16 * v, &z, 16); }
+        }
+    } else {
+#pragma unroll
+        for (int j = 1; j < FP_PX; ++j)
+            if (j >= shift) {
+#pragma unroll
+                for (int k = 0; k < CH; ++k) drow[CH * j + k] = (DstT)0;
+            }
+    }
+}
+
 #ifndef RWH_F4_WAVES
 #define RWH_F4_WAVES 8   // fits in 62 VGPRs without spilling: 8 waves per SIMD
 #endif
@@ -414,8 +442,8 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
     const int y2 = (int)__builtin_amdgcn_readlane(hy[0], 48), y3 = (int)__builtin_amdgcn_readlane(hy[FP_PX - 1], 63);
     const int hxmn = smin(smin(x0, x1), smin(x2, x3)), hxmx = smax(smax(x0, x1), smax(x2, x3));
     const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
-    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
-    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    const int xmn = (int)((uint32_t)smax(hxmn, 0) - MAGIC_HI), xmx = (int)((uint32_t)smax(hxmx, 0) - MAGIC_HI);   // (negative hi dwords:
+    const int ymn = (int)((uint32_t)smax(hymn, 0) - MAGIC_HI), ymx = (int)((uint32_t)smax(hymx, 0) - MAGIC_HI);   //  see fast8_body)
     // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row,
     // and the footprint (rows ymn..ymx+1, texels xmn..xmx+1) fits the slab
     const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) &
@@ -797,10 +825,26 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     //  whenever the source rows are)
     const int hxmn = smin(smin(x0, x1), smin(x2, x3)) & ~3, hxmx = smax(smax(x0, x1), smax(x2, x3));
     const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
-    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
-    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    // (a coordinate below -1.5 * 2^20 makes s + MAGIC negative: its hi dword is a negative int, the min -- clamped to 0 before
+    //  the subtraction, which would otherwise wrap around to a large POSITIVE texel index)
+    const int xmn = (int)((uint32_t)smax(hxmn, 0) - MAGIC_HI), xmx = (int)((uint32_t)smax(hxmx, 0) - MAGIC_HI);
+    const int ymn = (int)((uint32_t)smax(hymn, 0) - MAGIC_HI), ymx = (int)((uint32_t)smax(hymx, 0) - MAGIC_HI);
     // footprint: rows ymn..ymx+1, texels xmn..xmx+1, as nrows x C chunks of 4 texels
     using Win = F8Window<LOG_PW>;
+    // ---- the whole patch maps outside the source (2.6 % of a 4K frame's patches with the bench homography, 4.6 % of a 1080p
+    // frame's, 6.4 % of an 8K frame's: the corners of the warped quad's bounding box): W > 0 on the patch, so every pixel's
+    // coordinate lies in the corners' box, and a box wholly left / right / above / below the source means every pixel is
+    // masked -- zeros, with no staging, no coordinates for the other six pixels, no blend
+    if constexpr (!COMP) {
+        if (wpos & ((xmx < 0) | (xmn >= a.bound_w) | (ymx < 0) | (ymn >= a.bound_h))) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int first = tshift - (lcol + (PW / 2) * h);
+                zero_store<DstT, PSTR, CH>(drow + CH * (PW / 2) * h, store_any & (first <= 3 * PSTR), max(first, 0));
+            }
+            return;
+        }
+    }
     const int nrows = ymx - ymn + 2, C = (xmx - xmn + 5) >> 2;
     // strictly inside: 0 <= floor(s) <= bound-2 on both axes, tap rows above the last source row (a chunk may read
     // up to 9 bytes past the footprint's last texel: never past the row below), and the footprint fits the window
@@ -1027,8 +1071,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 const int hy2 = (int)__builtin_amdgcn_readlane(lhy, 64 - LPR), hy3 = (int)__builtin_amdgcn_readlane(rhy, 63);
                 const int qxmn = smin(smin(hx0, hx1), smin(hx2, hx3)) & ~3, qxmx = smax(smax(hx0, hx1), smax(hx2, hx3));
                 const int qymn = smin(smin(hy0, hy1), smin(hy2, hy3)), qymx = smax(smax(hy0, hy1), smax(hy2, hy3));
-                const int sxmn = (int)((uint32_t)qxmn - MAGIC_HI), sxmx = (int)((uint32_t)qxmx - MAGIC_HI);
-                const int symn = (int)((uint32_t)qymn - MAGIC_HI), symx = (int)((uint32_t)qymx - MAGIC_HI);
+                const int sxmn = (int)((uint32_t)smax(qxmn, 0) - MAGIC_HI), sxmx = (int)((uint32_t)smax(qxmx, 0) - MAGIC_HI);
+                const int symn = (int)((uint32_t)smax(qymn, 0) - MAGIC_HI), symx = (int)((uint32_t)smax(qymx, 0) - MAGIC_HI);
                 const int hrows = symx - symn + 2, hC = (sxmx - sxmn + 5) >> 2;
                 const bool hfits = (sxmn >= 0) & (sxmx < a.bound_w - 1) & (symn >= 0) & (symx < min(a.bound_h - 1, a.src_h - 2)) &
                                    (hrows >= Win::RPP) & (hrows <= Win::ROWS) & (hC <= Win::LPRW);
@@ -1269,8 +1313,8 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
     const int hxmn = smin(smin(x0, x1), smin(x2, x3)) & ~3, hxmx = smax(smax(x0, x1), smax(x2, x3));   // window from a multiple of 4 texels
     const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
-    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);
-    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    const int xmn = (int)((uint32_t)smax(hxmn, 0) - MAGIC_HI), xmx = (int)((uint32_t)smax(hxmx, 0) - MAGIC_HI);   // (negative hi dwords:
+    const int ymn = (int)((uint32_t)smax(hymn, 0) - MAGIC_HI), ymx = (int)((uint32_t)smax(hymx, 0) - MAGIC_HI);   //  see fast8_body)
     // footprint rows ymn..ymx, texels xmn..xmx (a corner within NN_TIE of a boundary may really round one further:
     // such pixels never use the slab); one row of slack below for the 9 bytes a chunk may read past its last texel
     using Win = F8Window<LOG_PW>;

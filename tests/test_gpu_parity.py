@@ -1293,6 +1293,40 @@ def test_warp_minification_halves_per_image(gpu, monkeypatch):
     assert any("fast8h" in p for p in plans) and any("fast8<" in p for p in plans), plans
 
 
+@pytest.mark.parametrize("c0", [127.002, 127.001, 127.0008])
+def test_warp_patch_next_to_the_horizon(gpu, c0, monkeypatch):
+    """A 128-pixel patch whose denominator stays positive but reaches 0.002 at its last column: the source x coordinate runs
+    from +3 (valid) to -2.3e6.  Below -1.5 * 2^20 the magic-number sum s + MAGIC turns negative and its high dword no longer
+    encodes floor(s); for s in (-3 * 2^20, -1.5 * 2^20) a 32-bit subtraction used to wrap the footprint's minimum around to a
+    large POSITIVE texel index (round 3: clamped before the subtraction).  Every fast kernel, every patch shape, against the
+    exact float64 kernel; and whole patches far outside the source (the early exit of round 3) come out as zeros."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(3)
+    img = rng.integers(1, 256, (64, 64, 3), dtype=np.uint8)
+    src = torch.from_numpy(img).to(gpu)
+    ih = np.array([[-40.0, 0, 400.0], [-5.0, 0, 5 * c0], [-1.0, 0, c0]])      # x = (400 - 40 c) / (c0 - c), y = 5, W = c0 - c
+    grid = kernels.Grid(0, 255, 256, 0, 15, 16)
+    for shape in ("7", "6", "5", None):
+        _force_shape(shape)
+        ex = kernels.warp_backward(src, ih, grid, (64, 64), "bilinear", torch.float64, zero_origin=False, exact=True)
+        assert int((ex != 0).any(dim=2).sum()) == 176            # columns 0..10 of 16 rows
+        f = kernels.warp_backward(src, ih, grid, (64, 64), "bilinear", torch.float32, zero_origin=False)
+        u = kernels.warp_backward(src, ih, grid, (64, 64), "bilinear", torch.uint8, zero_origin=False)
+        assert float((f.double() - ex).abs().max()) < 1e-4 * 255, shape
+        assert int((u.to(torch.int16) - ex.to(torch.uint8).to(torch.int16)).abs().max()) <= 1, shape
+        nn_e = kernels.warp_backward(src, ih, grid, (64, 64), "nn", torch.uint8, zero_origin=False, exact=True)
+        nn_f = kernels.warp_backward(src, ih, grid, (64, 64), "nn", torch.uint8, zero_origin=False)
+        assert torch.equal(nn_e, nn_f), shape
+    _force_shape(None)
+    # far outside on each side: zeros (uint8, float32, RGBA)
+    img4 = torch.from_numpy(rng.integers(1, 256, (64, 64, 4), dtype=np.uint8)).to(gpu)
+    for tx, ty in ((-3.0e6, 0.0), (3.0e6, 0.0), (0.0, -2.0e5), (0.0, 7.0e4), (-2.0e6, 3.0e6)):
+        ih2 = np.array([[1.0, 0.001, tx], [0.002, 1.0, ty], [1e-6, 0, 1.0]])
+        for s_, dt in ((src, torch.uint8), (src, torch.float32), (img4, torch.uint8)):
+            out = kernels.warp_backward(s_, ih2, grid, (64, 64), "bilinear", dt, zero_origin=False)
+            assert int(torch.count_nonzero(out)) == 0, (tx, ty, dt)
+
+
 def _oracle_nn_on_grid(img, inv_h, xs, ys, bound_hw):
     """homography.py:166-179 with the nearest-neighbour interpolator on an arbitrary output grid."""
     from oracle import rwh_oracle as orc
