@@ -96,6 +96,9 @@ RWH_API int rwh_lab_clock_probe(uint64_t* d_out, double milliseconds, void* stre
  * (which tests the unrounded float64, homography.py:131) returns 0.  On a generic map that is one pixel in ~10^9; an
  * axis-aligned map whose inv(H) carries 1e-16 round-off (a rotation by numpy's pi) can put a whole border row or column
  * there.  RWH_WARP_EXACT reproduces the reference's decision bit for bit (tests: test_warp_image_edge_band_vs_oracle).
+ * Non-finite inv_h entries: a pixel whose denominator is +-Inf maps to (0, 0) in IEEE arithmetic (finite / Inf = 0) and shows
+ * source texel (0,0) in the reference and in the exact kernels; the fast bilinear kernels mask it (0).  The reference blanks
+ * texel (0,0) before it samples (RWH_WARP_ZERO_ORIGIN), so the two differ only for a caller that skips the blanking.
  *
  * Only rows [row_begin, row_end) are produced; d_dst points at row `row_begin`
  * of image 0 and image b at d_dst + b*dst_image_stride (bytes).  This is the
