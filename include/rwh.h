@@ -149,7 +149,8 @@ RWH_API int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, int
  *   HomoModel.fit(X[:,idx], Y[:,idx])   ransac.py:178-180 -> 52
  *   calcHomography / calc_corresp        homography.py:71-88 / 4-14
  * d_pts_a, d_pts_b: M x 2 float32 (the `matchespoints` layout, points in rows);
- * d_idx: K x 4 int32 sample indices in [0, M) (drawn by the caller from numpy's
+ * d_idx: K x 4 int32 sample indices in [0, M) -- a PRECONDITION: device tables are not range-checked (the host entry points
+ *   rwh_ransac_run / rwh_host_dlt4_svd and the Python mirror check theirs) -- (drawn by the caller from numpy's
  * legacy generator for parity, ransac.py:177);
  * d_h: K x 9 float32, row-major 3x3 with h[8] == 1;
  * d_flags: K bytes, bit 0 = repeated index in the sample, bit 1 = non-finite

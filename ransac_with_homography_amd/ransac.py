@@ -508,7 +508,20 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
     needs = torch.tensor(needs_host, dtype=torch.int32, device=dev)
     ws = kernels.BatchWorkspace(P, int(k), max(max(sizes), 1), dev)
     if idx is not None:
-        table = torch.from_numpy(np.stack([np.asarray(t)[:, :4].astype(np.int32) for t in idx])).to(dev)   # fit on the first four
+        if len(idx) != P:
+            raise ValueError("idx: one [k, n] table per problem (%d tables for %d problems)" % (len(idx), P))
+        tables = []
+        for p_, t in enumerate(idx):        # numpy's own indexing rules (ransac.py:178 `data[:, idx]`): negative indices wrap, others raise
+            t = np.asarray(t)
+            if t.ndim != 2 or t.shape[0] != int(k) or t.shape[1] < 4:
+                raise ValueError("idx[%d]: expected a [%d, >= 4] integer array, got shape %s" % (p_, int(k), t.shape))
+            m_ = sizes[p_]
+            if t.size and (int(t.min()) < -m_ or int(t.max()) >= m_):
+                bad = int(t.max()) if int(t.max()) >= m_ else int(t.min())
+                raise IndexError("index %d is out of bounds for axis 1 with size %d" % (bad, m_))
+            tables.append(np.where(t < 0, t + m_, t))
+        idx = tables
+        table = torch.from_numpy(np.stack([t[:, :4].astype(np.int32) for t in idx])).to(dev)   # fit on the first four
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, idx=table)
     else:
         kernels.ransac_batched(pa, pb, torch.from_numpy(offsets).to(dev), needs, _weak_threshold(th), method, ws, seed=seed,

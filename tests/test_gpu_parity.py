@@ -516,6 +516,20 @@ def test_batched_search_equals_single_searches(gpu, matches, method):
         H, inl, cnt = rs.RANSAC(rs.HomoModel(th=th, d=d, n=4), k=K).run([X, Y], method=method)
         assert int(got[p][2]) == int(cnt) and np.array_equal(got[p][1][0], inl[0]), p
         assert np.array_equal(got[p][0], H), p
+    # the caller's tables follow numpy's indexing rules (ransac.py:178 `data[:, idx]`): negative indices wrap, others raise
+    wrapped = [np.where(np.arange(t.size).reshape(t.shape) % 7 == 0, t - sizes[p], t) for p, t in enumerate(tables)]
+    again = rmod.run_batch(probs, th=th, d=d, k=K, method=method, idx=wrapped)
+    for p in range(len(probs)):
+        assert int(again[p][2]) == int(got[p][2]) and np.array_equal(again[p][0], got[p][0]), p
+    bad = [t.copy() for t in tables]
+    bad[1][5, 2] = sizes[1]
+    with pytest.raises(IndexError):
+        rmod.run_batch(probs, th=th, d=d, k=K, method=method, idx=bad)
+    bad[1][5, 2] = -sizes[1] - 1
+    with pytest.raises(IndexError):
+        rmod.run_batch(probs, th=th, d=d, k=K, method=method, idx=bad)
+    with pytest.raises(ValueError):
+        rmod.run_batch(probs, th=th, d=d, k=K, method=method, idx=tables[:-1])
 
 
 def test_batched_device_sampling(gpu, matches):
