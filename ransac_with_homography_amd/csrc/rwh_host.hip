@@ -9,7 +9,9 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <atomic>
 #include <thread>
+#include <unistd.h>
 #include <vector>
 #include "rwh.h"
 
@@ -55,7 +57,21 @@ void solve_range(dgesdd_t dgesdd, const float* pa, const float* pb, const int32_
 // per call.  Chunks of a batch are handed out under a mutex; the caller works on chunks too and returns when all are done.
 class HostPool {
   public:
-    static HostPool& get() { static HostPool* p = new HostPool; return *p; }     // never destroyed: workers may outlive main()
+    // never destroyed: workers may outlive main().  A forked child gets a pool of its own on first use: the parent's worker
+    // threads do not exist in it (and its mutexes may have been held at the fork).  Two threads racing on the very first call
+    // may create two pools; both work, one is leaked.
+    static HostPool& get() {
+        static std::atomic<HostPool*> cur{nullptr};
+        static std::atomic<long> owner{0};
+        HostPool* p = cur.load(std::memory_order_acquire);
+        const long me = (long)getpid();
+        if (!p || owner.load(std::memory_order_acquire) != me) {
+            p = new HostPool;
+            cur.store(p, std::memory_order_release);
+            owner.store(me, std::memory_order_release);
+        }
+        return *p;
+    }
     // run job(chunk) for chunk = 0 .. n_chunks-1 on up to `threads` threads (the caller included)
     void run(int n_chunks, int threads, const std::function<void(int)>& job) {
         std::lock_guard<std::mutex> serial(run_mu_);                            // one batch at a time

@@ -128,6 +128,30 @@ def test_native_host_solver_is_numpy_svd(matches):
         assert H.dtype == np.float32 and np.array_equal(H.reshape(9).view(np.uint32), g["H"][i].view(np.uint32))
 
 
+def test_native_host_solver_survives_a_fork(matches):
+    """The library's one piece of state is its pool of host worker threads.  A forked child has none of the parent's
+    threads: it must get a pool of its own and return the same bits (not wait for workers that do not exist)."""
+    import os
+    from ransac_with_homography_amd import _lapack
+    ptsA, ptsB = matches
+    g = load_golden("g2_hyp_seed0")
+    if _lapack.dgesdd_address() is None:
+        pytest.skip("numpy's LAPACK symbol not found")
+    want = g["H"][:4000].view(np.uint32)
+    assert np.array_equal(impl.svd_hypotheses(ptsA, ptsB, g["idx"][:4000], threads=5).view(np.uint32), want)     # the pool now has workers
+    pid = os.fork()
+    if pid == 0:
+        ok = False
+        try:
+            import signal
+            signal.alarm(60)                                                  # a hang ends the child, and the test fails
+            ok = np.array_equal(impl.svd_hypotheses(ptsA, ptsB, g["idx"][:4000], threads=5).view(np.uint32), want)
+        finally:
+            os._exit(0 if ok else 1)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0, status
+
+
 def test_illcond_flag_and_settle_on_lattice_problems(oracle_scorer):
     """Ill-conditioned samples WITHOUT a repeated index (three collinear source points, equal coordinates at different
     indices): K1's elimination returns a finite H that has nothing to do with LAPACK's (counts apart by hundreds).  With
