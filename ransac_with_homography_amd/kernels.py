@@ -5,6 +5,7 @@ torch is plumbing here (device memory, streams); every computation below happens
 inside librwh_hip.so.
 """
 import ctypes
+import threading
 import math
 
 import numpy as np
@@ -191,7 +192,7 @@ def ransac_search(pts_a, pts_b, idx, th, loss, need, ws, hyp_base=0, reset_best=
     return ws
 
 
-_pinned_run_ws = {}
+_pinned_run_ws = threading.local()      # per thread: two threads inside rwh_ransac_run (ctypes drops the GIL) must not share a host workspace
 
 
 class RunWorkspace:
@@ -209,11 +210,12 @@ class RunWorkspace:
         self.off = list(off)
         self.dev = torch.empty(self.off[self.D_END], dtype=torch.uint8, device=device)
         key = (self.m, self.k)
-        if key not in _pinned_run_ws:
-            if len(_pinned_run_ws) > 8:
-                _pinned_run_ws.clear()
-            _pinned_run_ws[key] = torch.empty(self.off[self.H_END], dtype=torch.uint8, pin_memory=True)
-        self.host = _pinned_run_ws[key]
+        cache = _pinned_run_ws.__dict__.setdefault("ws", {})
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            cache[key] = torch.empty(self.off[self.H_END], dtype=torch.uint8, pin_memory=True)
+        self.host = cache[key]
 
     def _dview(self, which, nbytes, dtype):
         return self.dev[self.off[which]:self.off[which] + nbytes].view(dtype)

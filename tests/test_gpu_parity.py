@@ -1775,6 +1775,42 @@ def test_ransac_run_random_problem_families_vs_oracle(gpu):
             assert res[0] == res[1], (case, kind, M, th, d, k, n, m, seed, res[0][:2], res[1][:2])
 
 
+def test_ransac_run_from_several_threads(gpu, matches):
+    """rwh_ransac_run is called with the GIL released: four Python threads running searches of the SAME size at once (a server
+    handling requests) must each get the result of their own sequential run -- the page-locked host workspace is cached per
+    thread, the library's host pool serialises the LAPACK batches."""
+    import threading
+    from ransac_with_homography_amd import _lapack, kernels
+    from ransac_with_homography_amd import ransac as rmod
+    ptsA, ptsB = matches
+    addr = _lapack.dgesdd_address()
+    if addr is None:
+        pytest.skip("numpy's LAPACK symbol not found: RANSAC.run uses the Python driver")
+    pa, pb = np.ascontiguousarray(ptsA, np.float32), np.ascontiguousarray(ptsB, np.float32)
+    m, k = pa.shape[0], 1500
+    need = kernels.need_count(m, 70, 4)
+    tables = [np.ascontiguousarray(np.random.default_rng(s).integers(0, m, (k, 4)), dtype=np.int32) for s in range(4)]
+
+    def one(t):
+        ws = kernels.RunWorkspace(m, k, gpu)
+        r = kernels.ransac_run(pa, pb, tables[t], 5.0, "fwd", need, rmod.RESCORE_MARGIN, ws, addr, 4)
+        return r[:6] + (r[6].tolist(), ws.host_counts(settled=True).tolist())
+    want = [one(t) for t in range(4)]
+    for rep in range(5):
+        got, errs = [None] * 4, []
+
+        def work(t):
+            try:
+                for _ in range(6): got[t] = one(t)
+            except Exception as e:      # noqa: BLE001 -- reported below
+                errs.append(e)
+        ths = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+        for th_ in ths: th_.start()
+        for th_ in ths: th_.join()
+        assert not errs, errs
+        assert got == want, rep
+
+
 def test_native_and_python_run_drivers_agree(gpu, matches):
     """rwh_ransac_run (the native driver RANSAC.run uses) against its Python twin (`RANSAC._run_python_driver`: the same upload /
     search / presettle / settle sequence step by step): identical winner, early flag, count, inlier list, settle statistics and
