@@ -1775,6 +1775,38 @@ def test_ransac_run_random_problem_families_vs_oracle(gpu):
             assert res[0] == res[1], (case, kind, M, th, d, k, n, m, seed, res[0][:2], res[1][:2])
 
 
+def test_warp_output_beyond_4GB(gpu):
+    """A single image whose output passes 2^32 bytes (36 000 x 40 000 RGB u8 = 4.32 GB; MI355X has 288 GB): the staged kernels
+    address their output with 32-bit lane offsets and hand such a launch to the generic kernel (64-bit offsets); row shards of
+    the same warp are small enough for the staged kernel again.  Shards from the top, the 2^32-byte line and the bottom agree
+    with the whole launch within 1 LSB, and a float32 sample of the same rows agrees with the exact kernel."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(8)
+    sh, sw, oh, ow = 300, 400, 36000, 40000
+    src = torch.from_numpy(rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)).to(gpu)
+    # (every coordinate strictly inside the source: no mask-edge band, where fast and exact kernels may differ -- rwh.h)
+    inv = np.array([[sw / ow * 0.98, 1e-4, 1.5], [2e-5, sh / oh * 0.97, 2.25], [1e-8, 2e-8, 1.0]])
+    grid = kernels.Grid(0, ow - 1, ow, 0, oh - 1, oh)
+    assert kernels.warp_plan((sh, sw, 3), torch.uint8, inv, grid, (sh, sw), "bilinear", torch.uint8).startswith("rwh::warp_generic")
+    assert kernels.warp_plan((sh, sw, 3), torch.uint8, inv, grid, (sh, sw), "bilinear", torch.uint8, rows=(0, 512)).startswith("rwh::warp_rgb8_fast8")
+    whole = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8, zero_origin=False)
+    assert whole.shape == (oh, ow, 3) and whole.numel() > (1 << 32)
+    line = (1 << 32) // (3 * ow)          # the row that holds byte 2^32
+    for r0, r1 in ((0, 256), (line - 128, line + 128), (oh - 300, oh)):
+        part = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.uint8, zero_origin=False, rows=(r0, r1))
+        d = (whole[r0:r1].to(torch.int16) - part.to(torch.int16)).abs()
+        assert int(d.max()) <= 1 and float((d != 0).float().mean()) < 0.02, (r0, r1, int(d.max()))
+        ex = kernels.warp_backward(src, inv, grid, (sh, sw), "bilinear", torch.float64, zero_origin=False, exact=True, rows=(r0, r0 + 16))
+        d2 = (whole[r0:r0 + 16].to(torch.int16) - ex.to(torch.uint8).to(torch.int16)).abs()
+        assert int(d2.max()) <= 1, (r0, int(d2.max()))
+    assert int(torch.count_nonzero(whole[oh - 4:])) > 0            # the last rows were written
+    del whole
+    nn = kernels.warp_backward(src, inv, grid, (sh, sw), "nn", torch.uint8, zero_origin=False)
+    for r0, r1 in ((line - 64, line + 64), (oh - 100, oh)):
+        part = kernels.warp_backward(src, inv, grid, (sh, sw), "nn", torch.uint8, zero_origin=False, rows=(r0, r1))
+        assert torch.equal(nn[r0:r1], part), (r0, r1)
+
+
 def test_ransac_run_from_several_threads(gpu, matches):
     """rwh_ransac_run is called with the GIL released: four Python threads running searches of the SAME size at once (a server
     handling requests) must each get the result of their own sequential run -- the page-locked host workspace is cached per
