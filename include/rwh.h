@@ -99,6 +99,8 @@ RWH_API int rwh_lab_clock_probe(uint64_t* d_out, double milliseconds, void* stre
  * Non-finite inv_h entries: a pixel whose denominator is +-Inf maps to (0, 0) in IEEE arithmetic (finite / Inf = 0) and shows
  * source texel (0,0) in the reference and in the exact kernels; the fast bilinear kernels mask it (0).  The reference blanks
  * texel (0,0) before it samples (RWH_WARP_ZERO_ORIGIN), so the two differ only for a caller that skips the blanking.
+ * A NaN coordinate (0 / 0, Inf / Inf) escapes the reference's comparisons and makes it raise IndexError (it indexes with
+ * INT_MIN, homography.py:133-135); every kernel here returns 0 for such a pixel.
  *
  * Only rows [row_begin, row_end) are produced; d_dst points at row `row_begin`
  * of image 0 and image b at d_dst + b*dst_image_stride (bytes).  This is the

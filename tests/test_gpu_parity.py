@@ -1775,6 +1775,52 @@ def test_ransac_run_random_problem_families_vs_oracle(gpu):
             assert res[0] == res[1], (case, kind, M, th, d, k, n, m, seed, res[0][:2], res[1][:2])
 
 
+@pytest.mark.parametrize("block", range(3))
+def test_warp_exact_kernels_vs_oracle_next_to_the_horizon(gpu, block):
+    """The exact kernels are what tools/soak_horizon.py trusts: here they are held against the oracle itself, bit for bit, on
+    its kind of map -- a denominator that reaches ~0 within 1e-5 .. 0.5 px of a patch-lattice corner (coordinates up to 1e9,
+    both signs of W in the grid), scaled homographies, an infinite entry."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(500 + block)
+    compared = 0
+    for case in range(10):
+        sh, sw = int(rng.integers(40, 200)), int(rng.integers(40, 300))
+        img = rng.integers(0, 256, (sh, sw, 3), dtype=np.uint8)
+        img[0, 0] = 0                                        # (the reference blanks texel (0,0) before it samples)
+        ow, oh = int(rng.integers(128, 330)), int(rng.integers(16, 120))
+        pw = int(rng.choice([32, 64, 128])); ph = 512 // pw
+        cc = float(rng.integers(0, ow // pw + 1) * pw - rng.integers(0, 2)); rr = float(rng.integers(0, oh // ph + 1) * ph - rng.integers(0, 2))
+        delta = 10.0 ** rng.uniform(-5, -0.3) * rng.choice([-1, 1])
+        t = rng.uniform(0, 2 * np.pi)
+        nrm = np.array([np.cos(t), np.sin(t)])
+        g = 10.0 ** rng.uniform(-4, 0)
+        p0 = np.array([cc, rr]) + delta * nrm
+        w_row = np.array([g * nrm[0], g * nrm[1], -g * (nrm @ p0)]) * rng.choice([-1, 1])
+        A = rng.uniform(-1.5, 1.5, (2, 3)); A[:, 2] = rng.uniform(-50, 50, 2) + np.array([sw / 2, sh / 2]) * abs(w_row[2])
+        if case % 3 == 0: A[1] = w_row * rng.uniform(0, sh - 1)
+        if case % 3 == 1: A[0] = w_row * rng.uniform(0, sw - 1)
+        ih = np.vstack([A, w_row])
+        if case % 5 == 4: ih = ih * 10.0 ** rng.uniform(-280, 280)
+        if case == 7: ih[2, int(rng.integers(0, 3))] = np.inf
+        xs, ys = np.arange(ow, dtype=np.float64), np.arange(oh, dtype=np.float64)
+        grid = kernels.Grid(0, ow - 1, ow, 0, oh - 1, oh)
+        src = torch.from_numpy(img).to(gpu)
+        try:
+            with np.errstate(all="ignore"):
+                ref = _oracle_warp_on_grid(img, ih, xs, ys, (sh, sw))
+                ref_nn = _oracle_nn_on_grid(img, ih, xs, ys, (sh, sw))
+        except IndexError:          # a NaN coordinate (0 / 0, Inf / Inf) escapes the reference's mask and indexes with INT_MIN:
+            continue                # the reference raises where the kernels return 0 (rwh.h)
+        compared += 1
+        ex = kernels.warp_backward(src, ih, grid, (sh, sw), "bilinear", torch.float64, zero_origin=False, exact=True).cpu().numpy()
+        assert np.array_equal(ex, ref), (block, case, int((ex != ref).any(axis=2).sum()))
+        nn = kernels.warp_backward(src, ih, grid, (sh, sw), "nn", torch.uint8, zero_origin=False, exact=True).cpu().numpy()
+        assert np.array_equal(nn, ref_nn), (block, case, int((nn != ref_nn).any(axis=2).sum()))
+        nn_fast = kernels.warp_backward(src, ih, grid, (sh, sw), "nn", torch.uint8, zero_origin=False).cpu().numpy()
+        assert np.array_equal(nn_fast, ref_nn), (block, case)
+    assert compared >= 6, compared
+
+
 def test_warp_output_beyond_4GB(gpu):
     """A single image whose output passes 2^32 bytes (36 000 x 40 000 RGB u8 = 4.32 GB; MI355X has 288 GB): the staged kernels
     address their output with 32-bit lane offsets and hand such a launch to the generic kernel (64-bit offsets); row shards of
