@@ -657,9 +657,10 @@ inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // h
     return nrows >= 64 / lprw && nrows <= rows && ((ntex + 3) >> 2) <= lprw;
 }
 
-// Waves per SIMD the register allocator must leave room for.  uint8 output: 7 (73 VGPRs).  The 64-register / 8-wave build
-// of the first half of the round fits only by spilling a dozen scalars into VGPR lanes on the way in; with the border path
-// in the kernel the 7-wave build (72 VGPRs, no spills of either kind) is 0.8 % FASTER in a same-box A/B, and robust.
+// Waves per SIMD the register allocator must leave room for.  uint8 output: 7 (a budget of 73 VGPRs).  Round 2's blend needed 72
+// of them (its 64-register / 8-wave build fitted only by spilling a dozen scalars into VGPR lanes and was 0.8 % slower); round
+// 3's v_fma_mix_f32 blend keeps no converted taps and comes to 60 VGPRs under the same bound, so 8 waves per SIMD are
+// resident after all (LDS: 8 blocks x 20 160 B per CU) -- no spills of either kind.
 // 32 x 16 patches 6 (their windows need the LDS).  float32 output (3 KB more LDS per wave for the re-deal) and the
 // compositor: LDS allows 5 (4 for 32 x 16 patches) and 6.
 template <typename DstT, int LOG_PW> constexpr int f8_waves() {
