@@ -1323,6 +1323,18 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const bool staged = wpos & (xmn >= 0) & (xmx <= a.bound_w - 1) & (ymn >= 0) & (ymx <= min(a.bound_h - 1, a.src_h - 2)) &
                         (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
 
+    // the whole patch rounds to indices a full texel or more outside the source (W > 0: every pixel lies in the corners' box;
+    // the margin of one texel covers the 3e-10 px between the magic-number rounding and the reference's own formula): zeros,
+    // without the per-pixel IEEE divisions of the fallback below (6.4 % of an 8K frame's patches with the bench homography)
+    if (wpos & ((xmx <= -3) | (xmn >= a.bound_w + 1) | (ymx <= -3) | (ymn >= a.bound_h + 1))) {
+        const uint32_t zero[FP_PX] = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int first = tshift - (lcol + (PW / 2) * h);
+            nn_store(zero, drow + 3 * (PW / 2) * h, store_any & (first < 4), first);
+        }
+        return;
+    }
     if (!staged) {                                          // every pixel by the reference's formula
 #pragma unroll
         for (int h = 0; h < 2; ++h) {

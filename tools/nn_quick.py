@@ -1,10 +1,11 @@
-"""Developer probe: the nearest-neighbour warp kernel on the bench geometry, 4K / 1080p / 8K."""
+"""Developer probe: the nearest-neighbour warp kernel on the bench geometry, 4K / 1080p / 8K.   RWH_LIB=<another build of the library>"""
 import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_with_homography_amd import _lib, kernels
 from ransac_with_homography_amd import homography as hg
 H_S = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+if os.environ.get("RWH_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["RWH_LIB"])
 dev = _lib.require_gpu()
 for (W, Hh, F) in ((3840, 2160, 16), (1920, 1080, 64), (7680, 4320, 4)):
     g = torch.Generator(device=dev).manual_seed(3)
