@@ -403,6 +403,8 @@ def ransac_run(X, Y, th=5, d=50, n=4, k=1000, method="reproj"):
             break
         if cnt > best:
             best, best_mask, best_it = cnt, mask, it
+    if k <= 0:          # ransac.py:203 reads `lenalsoIninears`, which only the loop body assigns
+        raise UnboundLocalError("local variable 'lenalsoIninears' referenced before assignment")
     inliers = np.where(best_mask)
     # HomoModel.fit's size check (ransac.py:38): exactly n columns, or more than n with collective=True -- a winner with
     # fewer inliers than the sample size n (possible for n > 4: the model is fitted on four points) fails here

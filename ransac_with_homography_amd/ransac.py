@@ -351,12 +351,15 @@ class RANSAC(object):
         assert mx == my, "data observation not consistent!"
         if method not in _lib.RWH_LOSS:
             exit("Invalid method!")
+        k = int(self.k)
+        if k <= 0:      # the loop body never runs and ransac.py:203 reads the count it would have assigned
+            raise UnboundLocalError("local variable 'lenalsoIninears' referenced before assignment")
         if self.n < 4:
-            # ransac.py:180 -> homography.py:9: calc_corresp reads u[3] of an n-point sample
+            # the first iteration draws its sample (ransac.py:177), then ransac.py:180 -> homography.py:9: calc_corresp reads u[3]
+            np.random.randint(0, mx, self.n)
             raise IndexError("index 3 is out of bounds for axis 0 with size %d" % self.n)
         dev = _lib.require_gpu()
         need = mx * self.d / 100 + self.n
-        k = int(self.k)
 
         # sampling: identical stream to k successive randint(0, mx, n) calls (ransac.py:177); the model is fitted on the
         # first four of the n sampled correspondences (ransac.py:180 -> homography.py:4-14)
@@ -364,6 +367,22 @@ class RANSAC(object):
         idx_host = np.random.randint(0, mx, (k, self.n))
 
         pa_host, pb_host = _points_rows(X), _points_rows(Y)
+        # A sample that holds a NaN coordinate makes the reference's SVD raise LinAlgError at ITS iteration (homography.py:81:
+        # LAPACK's dgesdd rejects a matrix with a NaN) -- unless an earlier iteration has taken the early exit.  Such samples are
+        # known from the index table: search the iterations before the first of them, and raise where the reference would.
+        # (+-Inf coordinates pass LAPACK's check: those samples are solved like any other flagged sample.)
+        first_bad = None
+        nonfinite = np.isnan(pa_host).any(axis=1) | np.isnan(pb_host).any(axis=1)
+        if nonfinite.any():
+            bad_rows = nonfinite[idx_host[:, :4]].any(axis=1)
+            if bad_rows.any():
+                first_bad = int(np.argmax(bad_rows))
+                if first_bad == 0:
+                    np.random.set_state(rng_state)
+                    np.random.randint(0, mx, (1, self.n))
+                    raise np.linalg.LinAlgError("SVD did not converge")
+                k = first_bad
+                idx_host = idx_host[:k]
         idx32 = np.ascontiguousarray(idx_host[:, :4], dtype=np.int32)
         need_i = kernels.need_count(mx, self.d, self.n)
         th = _weak_threshold(self.th)
@@ -385,12 +404,17 @@ class RANSAC(object):
         if early:  # leave the generator where the reference's `break` would
             np.random.set_state(rng_state)
             np.random.randint(0, mx, (winner + 1, self.n))
+        elif first_bad is not None:  # no early exit before the sample whose SVD fails
+            np.random.set_state(rng_state)
+            np.random.randint(0, mx, (first_bad + 1, self.n))
+            raise np.linalg.LinAlgError("SVD did not converge")
         elif k and counts_host[k - 1] < need:  # ransac.py:203-204 tests the LAST iteration's count
             print("Warning:: fitting model does not exceed required threshold %d vs %d" % (totalfit, need))
 
         if winner is None:
-            # ransac.py:206-208 with inliers_pos_final = None: np.where(None) -> empty -> fit asserts
-            inliers = (np.array([], dtype=np.int64),)
+            # ransac.py:206 with inliers_pos_final = None: whatever the installed numpy makes of np.where(None) -- an empty index
+            # (then the refit asserts, ransac.py:38) up to numpy 2.0, ValueError from 2.1 on
+            inliers = np.where(None)
             totalfit = 0
         else:
             words = mask_words

@@ -444,8 +444,68 @@ def g13(ptsA, ptsB):
     print("g13 count", int(cnt), "winner", win)
 
 
+def edge_cases():
+    """Inputs of g14: the corners of RANSAC.run's input space (name, ptsA [M,2] float32, ptsB, th, d, n, k)."""
+    rng = np.random.default_rng(77)
+    Hs = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+
+    def pair(M, noise=0.5):
+        G = rng.uniform(0, 800, (M, 2))
+        P = np.concatenate([G, np.ones((M, 1))], 1) @ Hs.T
+        return G.astype(np.float32), (P[:, :2] / P[:, 2:3] + rng.normal(0, noise, (M, 2))).astype(np.float32)
+    cases = []
+    for M in (0, 1, 2, 3, 4, 5):
+        A, B = pair(M)
+        cases.append(("M%d" % M, A, B, 5, 1, 4, 30))
+    A, B = pair(60)
+    for i, (th, d, n, k) in enumerate(((5, 20, 4, 0), (5, 20, 4, 1), (0, 20, 4, 50), (-1, 20, 4, 50), (1e30, 20, 4, 50), (5, 0, 4, 50),
+                                       (5, 1000, 4, 50), (5, 20, 60, 20), (5, 20, 61, 20), (2.5, 20.5, 4, 50), (5, 20, 3, 20))):
+        cases.append(("par%d" % i, A, B, th, d, n, k))
+    same = np.tile(np.array([[10.0, 20.0]], np.float32), (40, 1))
+    cases.append(("allequal", same, same.copy(), 5, 20, 4, 40))
+    line = np.stack([np.arange(50, dtype=np.float32) * 7, np.arange(50, dtype=np.float32) * 3], 1)
+    cases.append(("collinear", line, line + 1.0, 5, 20, 4, 40))
+    for name, bad in (("nan", np.nan), ("pinf", np.inf), ("ninf", -np.inf)):
+        A2, B2 = A.copy(), B.copy()
+        A2[7, 0] = bad; B2[13, 1] = bad
+        cases.append((name, A2, B2, 5, 20, 4, 60))
+    cases.append(("ragged", A, B[:-1], 5, 20, 4, 10))
+    return cases
+
+
+def g14():
+    """What the reference itself does at the corners of RANSAC.run's input space (seed 4242, 'fwd' and 'reproj'): the result
+    (count, inlier list, where the run left numpy's generator) or the TYPE of the exception it raises -- a k of 0 reads a
+    variable the loop never assigned, no hypothesis with an inlier makes np.where(None) the index (an error from numpy 2.1
+    on), a NaN coordinate makes LAPACK's SVD fail at the iteration that samples it, ..."""
+    import contextlib
+    import io
+    out = {"numpy_version": np.array(np.__version__)}
+    names = []
+    for name, A, B, th, d, n, k in edge_cases():
+        out[name + "_A"] = A; out[name + "_B"] = B
+        out[name + "_par"] = np.array([th, d, n, k], dtype=np.float64)
+        names.append(name)
+        for m in ("fwd", "reproj"):
+            np.random.seed(4242)
+            key = "%s_%s" % (name, m)
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                try:
+                    model = ref_r.HomoModel(th=th, d=d, n=n)
+                    H, inl, cnt = ref_r.RANSAC(model, k=k).run([A.T, B.T], method=m)
+                    out[key + "_outcome"] = np.array("ok")
+                    out[key + "_count"] = np.int64(cnt); out[key + "_inliers"] = np.asarray(inl[0]).astype(np.int64)
+                    out[key + "_H"] = np.asarray(H, np.float64)
+                except Exception as e:      # noqa: BLE001 -- the type is the datum
+                    out[key + "_outcome"] = np.array(type(e).__name__)
+            out[key + "_next_draw"] = np.int64(np.random.randint(0, 1 << 30))
+            print(key, str(out[key + "_outcome"]), int(out.get(key + "_count", -1)))
+    out["names"] = np.array(names)
+    save("g14_edge_cases", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -459,6 +519,7 @@ def main():
     if "g11" in which: g11()
     if "g12" in which: g12()
     if "g13" in which: g13(ptsA, ptsB)
+    if "g14" in which: g14()
 
 
 if __name__ == "__main__":

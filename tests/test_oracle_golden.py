@@ -191,3 +191,34 @@ def test_oracle_ransac_illcond_config4x8_and_n6(matches):
         assert np.random.randint(0, 1 << 30) == int(g[key + "_next_draw"])
     with pytest.raises(IndexError):
         orc.calc_homography(ptsA[:3], ptsB[:3])
+
+
+def test_oracle_ransac_edge_cases_g14():
+    """g14: what the unmodified reference does at the corners of RANSAC.run's input space -- k = 0 (UnboundLocalError), no
+    hypothesis with an inlier (np.where(None): ValueError from numpy 2.1 on), fewer than four correspondences, n < 4, a NaN
+    coordinate (LinAlgError at the iteration that samples it), Inf coordinates (no error), ragged inputs ...: the oracle gives
+    the same count, inlier list and generator position, or raises the same exception type."""
+    import contextlib
+    import io
+    g = load_golden("g14_edge_cases")
+    same_numpy = str(g["numpy_version"]).split(".")[:2] == np.__version__.split(".")[:2]
+    for name in [str(n) for n in g["names"]]:
+        A, B = g[name + "_A"], g[name + "_B"]
+        th, d, n, k = g[name + "_par"]
+        for m in ("fwd", "reproj"):
+            key = "%s_%s" % (name, m)
+            want = str(g[key + "_outcome"])
+            if want == "ValueError" and not same_numpy and A.shape[0] > 0:
+                continue                      # np.where(None) changed its mind between numpy versions
+            np.random.seed(4242)
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                try:
+                    H, inl, cnt, _ = orc.ransac_run(A.T, B.T, th=th, d=d, n=int(n), k=int(k), method=m)
+                    got = "ok"
+                except Exception as e:      # noqa: BLE001 -- the type is what is compared
+                    got = type(e).__name__
+            assert got == want, (key, got, want)
+            assert int(np.random.randint(0, 1 << 30)) == int(g[key + "_next_draw"]), key
+            if want == "ok":
+                assert int(cnt) == int(g[key + "_count"]) and np.array_equal(inl[0], g[key + "_inliers"]), key
+                assert np.allclose(H, g[key + "_H"], rtol=1e-6, atol=1e-9, equal_nan=True), key
