@@ -372,8 +372,10 @@ class RANSAC(object):
         # known from the index table: search the iterations before the first of them, and raise where the reference would.
         # (+-Inf coordinates pass LAPACK's check: those samples are solved like any other flagged sample.)
         first_bad = None
-        nonfinite = np.isnan(pa_host).any(axis=1) | np.isnan(pb_host).any(axis=1)
-        if nonfinite.any():
+        with np.errstate(invalid="ignore"):
+            maybe_nan = bool(np.isnan(pa_host.sum() + pb_host.sum()))      # one reduction per run (also NaN for Inf - Inf: sorted out below)
+        if maybe_nan:
+            nonfinite = np.isnan(pa_host).any(axis=1) | np.isnan(pb_host).any(axis=1)
             bad_rows = nonfinite[idx_host[:, :4]].any(axis=1)
             if bad_rows.any():
                 first_bad = int(np.argmax(bad_rows))
