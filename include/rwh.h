@@ -137,6 +137,19 @@ RWH_API int rwh_sample_points(const void* d_img, int src_h, int src_w, int chann
                       void* d_out, int dst_dtype, unsigned flags, void* stream);
 
 /*
+ * Would the REFERENCE raise IndexError on this warp?  Its interpolators index the image with every coordinate its mask lets
+ * through (homography.py:117-121, 131-135): bilinear reads texel x + 1, so a coordinate exactly ON the last column / row
+ * (the identity homography) indexes one past the image; a scan-mode `res` larger than the image lets coordinates beyond it
+ * through; a NaN coordinate passes the float mask and indexes with INT_MIN.  The kernels of this library clamp / mask such
+ * pixels; a drop-in host layer that wants the reference's error behaviour asks here first.  Coordinates by the exact
+ * kernels' arithmetic; no image access.  bound_h / bound_w: the reference's mask (NOT clipped to the source).
+ * *d_flag (device int32) = OR of: 1 an index past the last column (axis 1), 2 past the last row (axis 0), 4 a NaN coordinate.
+ */
+RWH_API int rwh_warp_index_check(int src_h, int src_w, const double* inv_h, double x0, double step_x, double x_last,
+                         double y0, double step_y, double y_last, int out_h, int out_w, int bound_h, int bound_w,
+                         int interp, int* d_flag, void* stream);
+
+/*
  * Which kernel rwh_warp_backward would launch for these arguments (same dispatch code, nothing is launched, no device
  * pointer is needed): writes the kernel's name as rocprofv3 prints it, e.g. "rwh::warp_rgb8_fast8<unsigned char, 6>"
  * (with one homography per image: the first group's kernel).  For reports (bench.py's roofline.kernel) and tests.

@@ -25,7 +25,7 @@ RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT = 0, 1, 2
 # every symbol include/rwh.h declares (tests check the library exports them all)
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama",
-           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout")
+           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check")
 
 
 class RwhUnavailable(RuntimeError):
@@ -59,6 +59,8 @@ def _bind(lib):
     lib.rwh_warp_plan.restype = i32
     lib.rwh_warp_plan.argtypes = [i32, i32, i32, i32, i32, c.POINTER(f64), i32, f64, f64, f64, f64, f64, f64,
                                   i32, i32, i32, i32, i32, i32, i32, i32, u32, c.c_char_p, i32]
+    lib.rwh_warp_index_check.restype = i32
+    lib.rwh_warp_index_check.argtypes = [i32, i32, c.POINTER(f64), f64, f64, f64, f64, f64, f64, i32, i32, i32, i32, i32, vp, vp]
     lib.rwh_sample_points.restype = i32
     lib.rwh_sample_points.argtypes = [vp, i32, i32, i32, i32, vp, vp, i64, i32, i32, i32, vp, i32, u32, vp]
     lib.rwh_dlt4_batched.restype = i32

@@ -736,7 +736,37 @@ extern "C" int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, 
     return st;
 }
 
+extern "C" int rwh_warp_index_check(int src_h, int src_w, const double* inv_h, double x0, double step_x, double x_last,
+                                    double y0, double step_y, double y_last, int out_h, int out_w, int bound_h, int bound_w,
+                                    int interp, int* d_flag, void* stream);
+
 namespace rwh {
+// Would the reference raise IndexError on this warp?  Coordinates by the exact kernels' arithmetic (warp_exact); no image access.
+// bits of *flag: 1 = an index past the last column (axis 1), 2 = past the last row (axis 0), 4 = a NaN coordinate (bilinear).
+__global__ __launch_bounds__(256) void index_check_kernel(const WarpArgs a, int interp, int* flag) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (long long)a.out_h * a.out_w) return;
+    const int r = (int)(i / a.out_w), c = (int)(i - (long long)r * a.out_w);
+    const double y = grid_coord(r, a.out_h, a.y0, a.step_y, a.y_last), x = grid_coord(c, a.out_w, a.x0, a.step_x, a.x_last);
+    const double X = fma(a.ih[1], y, a.ih[0] * x) + a.ih[2];
+    const double Y = fma(a.ih[4], y, a.ih[3] * x) + a.ih[5];
+    const double W = fma(a.ih[7], y, a.ih[6] * x) + a.ih[8];
+    const double sx = X / W, sy = Y / W;
+    int bits = 0;
+    if (interp == RWH_NEAREST) {                       // homography.py:110-119: the mask is on the integers, NaN -> INT_MIN is masked
+        const int xi = (int)(sx + 0.5), yi = (int)(sy + 0.5);
+        const bool unmasked = (xi >= 0) & (xi <= a.bound_w - 1) & (yi >= 0) & (yi <= a.bound_h - 1) & (sx == sx) & (sy == sy);
+        if (unmasked) bits = (xi > a.src_w - 1 ? 1 : 0) | (yi > a.src_h - 1 ? 2 : 0);
+    } else {                                           // homography.py:131-135: NaN passes the float mask and indexes with INT_MIN
+        const bool masked = (sx > (double)(a.bound_w - 1)) | (sx < 0.0) | (sy > (double)(a.bound_h - 1)) | (sy < 0.0);
+        if (!masked) {
+            if (!(sx == sx) || !(sy == sy)) bits = 4;
+            else bits = ((int)sx + 1 > a.src_w - 1 ? 1 : 0) | ((int)sy + 1 > a.src_h - 1 ? 2 : 0);
+        }
+    }
+    if (bits) atomicOr(flag, bits);
+}
+
 template <typename SrcT, int C>
 static int sample_dispatch(const unsigned char* img, int src_h, int src_w, int bound_h, int bound_w, const double* xs, const double* ys,
                            long long n, int interp, void* out, int dst_dtype, hipStream_t s) {
@@ -778,4 +808,23 @@ extern "C" int rwh_sample_points(const void* d_img, int src_h, int src_w, int ch
                              : sample_dispatch<unsigned char, 4>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s);
     return channels == 3 ? sample_dispatch<float, 3>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s)
                          : sample_dispatch<float, 4>(img, src_h, src_w, bh, bw, d_x, d_y, n, interp, d_out, dst_dtype, s);
+}
+
+extern "C" int rwh_warp_index_check(int src_h, int src_w, const double* inv_h, double x0, double step_x, double x_last,
+                                    double y0, double step_y, double y_last, int out_h, int out_w, int bound_h, int bound_w,
+                                    int interp, int* d_flag, void* stream) {
+    using namespace rwh;
+    if (!inv_h || !d_flag || src_h <= 0 || src_w <= 0 || out_h <= 0 || out_w <= 0 || bound_h <= 0 || bound_w <= 0) return RWH_E_INVALID;
+    if (interp != RWH_NEAREST && interp != RWH_BILINEAR) return RWH_E_INVALID;
+    WarpArgs a = {};
+    for (int i = 0; i < 9; ++i) a.ih[i] = inv_h[i];
+    a.x0 = x0; a.step_x = step_x; a.x_last = x_last; a.y0 = y0; a.step_y = step_y; a.y_last = y_last;
+    a.src_h = src_h; a.src_w = src_w; a.bound_h = bound_h; a.bound_w = bound_w;      // the bound is NOT clipped here: it is the reference's mask
+    a.out_h = out_h; a.out_w = out_w;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(d_flag, 0, sizeof(int), s) != hipSuccess) return RWH_E_LAUNCH;
+    const long long n = (long long)out_h * out_w;
+    if ((n + 255) / 256 >= (1ll << 31)) return RWH_E_UNSUPPORTED;
+    hipLaunchKernelGGL(index_check_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, a, interp, d_flag);
+    return check_launch();
 }

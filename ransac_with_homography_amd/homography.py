@@ -164,6 +164,11 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
         raise KeyError(convert)  # convertfunc[convert], homography.py:179 / 208
     inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))  # homography.py:172 / 203 (raises LinAlgError)
     src, was_numpy, np_dtype = _to_device(img)
+    true_hw = (int(src.shape[0]), int(src.shape[1]))
+    if true_hw[0] < 3 or true_hw[1] < 3:      # the kernels want 3 x 3 texels at least: zero rows / columns beyond the bounds, which
+        pad = torch.zeros((max(true_hw[0], 3), max(true_hw[1], 3), src.shape[2]), dtype=src.dtype, device=src.device)   # stay (h, w)
+        pad[:true_hw[0], :true_hw[1]] = src
+        src = pad
     exact = was_numpy if EXACT is None else bool(EXACT)
     if convert == "nn":
         out_dtype = src.dtype
@@ -171,11 +176,17 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
         out_dtype = torch.uint8 if u8_out else torch.float64
     else:
         out_dtype = torch.uint8 if u8_out else torch.float32
+    # numpy arrays in (the reference's own callers): where the reference's interpolator would index past the image -- a coordinate
+    # exactly on the last column / row, a scan `res` beyond the image, a NaN coordinate -- raise its IndexError (rwh.h)
+    flag = kernels.warp_index_check(true_hw, inv_h, grid, bound_hw, convert, src.device) if was_numpy else None
     out = kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=True, exact=exact)
     if not was_numpy:
         return out
     _blank_origin(img)
     res = _xfer.to_host(out)
+    bits = int(flag.item())
+    if bits:
+        kernels.raise_like_reference(bits, true_hw)
     if convert == "nn":
         return res if res.dtype == np_dtype else res.astype(np_dtype)
     return res if (u8_out or res.dtype == np.float64) else res.astype(np.float64)  # the reference's bilinear yields float64
@@ -246,6 +257,20 @@ def _sample(z_t, img, h, w, mh, mw, convert):
         return out
     _blank_origin(img)
     res = out.cpu().numpy()
+    # the reference indexes the image with every coordinate its mask lets through: raise where it would (see _warp, rwh.h)
+    ih_, iw_ = int(img.shape[0]), int(img.shape[1])
+    if convert == 'nn':
+        xi, yi = (zx + 0.5).to(torch.int64), (zy + 0.5).to(torch.int64)
+        u = (xi >= 0) & (xi <= w - 1) & (yi >= 0) & (yi <= h - 1) & ~torch.isnan(zx) & ~torch.isnan(zy)
+        bits = (1 if bool((u & (xi > iw_ - 1)).any()) else 0) | (2 if bool((u & (yi > ih_ - 1)).any()) else 0)
+    else:
+        u = ~((zx > w - 1) | (zx < 0) | (zy > h - 1) | (zy < 0))
+        nan = u & (torch.isnan(zx) | torch.isnan(zy))
+        fin = u & ~nan
+        bits = (4 if bool(nan.any()) else 0) | (1 if bool((fin & (zx.floor() + 1 > iw_ - 1)).any()) else 0) | \
+               (2 if bool((fin & (zy.floor() + 1 > ih_ - 1)).any()) else 0)
+    if bits:
+        kernels.raise_like_reference(bits, (ih_, iw_))
     return res if (convert == 'bilinear' or res.dtype == np_dtype) else res.astype(np_dtype)
 
 
@@ -427,13 +452,19 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
         q_dev = _xfer.to_device(imgQ, dev)
     exact = (not tens) if EXACT is None else bool(EXACT)    # numpy in: the bit-identical float64 kernel; tensors in: the fast one
     mode = 0 if paste else 1 if blending == 'Rate' else 2   # 'Gradient': the alpha ramp, exact kernel only
+    # (numpy in: transformImageH's bilinear warp of imgT raises IndexError in the reference where it indexes past the image)
+    flag = None if tens else kernels.warp_index_check((h, w), inv_h, kernels.Grid(mx, mx + wt - 1, wt, my, my + ht - 1, ht), (h, w), "bilinear", dev)
     out = kernels.stitch_panorama(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), (fh, fw),
                                   mode, blendrate, zero_origin=True, fast=not exact)
     if tens:
         return out
     if not blending:
         _blank_origin(imgT)            # transformImageH -> bilinear blanks the caller's texel (0,0) in the paste path
-    return _xfer.to_host(out)
+    res = _xfer.to_host(out)
+    bits = int(flag.item())
+    if bits:
+        kernels.raise_like_reference(bits, (h, w))
+    return res
 
 
 def cylindericlMap(img, f=1600):

@@ -98,6 +98,28 @@ def sample_points(img, xs, ys, bound_hw, interp, zero_origin=True):
     return out
 
 
+def warp_index_check(src_hw, inv_h, grid, bound_hw, interp, device):
+    """rwh_warp_index_check: enqueue the test "would the reference raise IndexError on this warp?" and return the device flag
+    (int32 [1]; read it after the warp: 1 = an index past the last column, 2 = past the last row, 4 = a NaN coordinate)."""
+    lib = _lib.load()
+    ih = np.ascontiguousarray(inv_h, dtype=np.float64).reshape(9)
+    flag = torch.empty(1, dtype=torch.int32, device=device)
+    check(lib.rwh_warp_index_check(int(src_hw[0]), int(src_hw[1]), ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)),
+                                   grid.x0, grid.step_x, grid.x_last, grid.y0, grid.step_y, grid.y_last, grid.out_h, grid.out_w,
+                                   int(bound_hw[0]), int(bound_hw[1]), INTERP[interp], _ptr(flag), _lib.stream_ptr()), "rwh_warp_index_check")
+    return flag
+
+
+def raise_like_reference(bits, src_hw):
+    """The IndexError numpy raises inside the reference's interpolators (homography.py:117-121, 133-135) for these flag bits."""
+    if bits & 4:
+        raise IndexError("index -2147483648 is out of bounds for axis 0 with size %d" % src_hw[0])
+    if bits & 2:
+        raise IndexError("index %d is out of bounds for axis 0 with size %d" % (src_hw[0], src_hw[0]))
+    if bits & 1:
+        raise IndexError("index %d is out of bounds for axis 1 with size %d" % (src_hw[1], src_hw[1]))
+
+
 def warp_plan(src_shape, src_dtype, inv_h, grid, bound_hw, interp, out_dtype, rows=None, exact=False):
     """Name of the kernel `warp_backward` launches for this configuration (rwh_warp_plan: the library's own dispatch,
     nothing is launched and no GPU is needed).  src_shape: (B, H, W, C) or (H, W, C)."""

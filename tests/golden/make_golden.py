@@ -504,8 +504,73 @@ def g14():
     save("g14_edge_cases", **out)
 
 
+def warp_edge_cases():
+    """Inputs of g15: (name, function name, image, args) at the corners of the warp entry points' input space."""
+    rng = np.random.default_rng(15)
+    img = rng.integers(1, 256, (9, 11, 3), dtype=np.uint8)
+    tiny = rng.integers(1, 256, (2, 2, 3), dtype=np.uint8)
+    three = rng.integers(1, 256, (3, 3, 3), dtype=np.uint8)
+    Hs = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+    t = np.pi / 2
+    Hm = {"identity": np.eye(3), "shift": np.array([[1, 0, 2.0], [0, 1, -3.0], [0, 0, 1]]), "scale2": np.diag([2.0, 2.0, 1.0]),
+          "mild": Hs, "rot90": np.array([[np.cos(t), -np.sin(t), 8.0], [np.sin(t), np.cos(t), 0.0], [0, 0, 1.0]]),
+          "mirror": np.array([[-1.0, 0, 10.0], [0, 1.0, 0], [0, 0, 1]]), "halfshift": np.array([[1, 0, 0.5], [0, 1, 0.25], [0, 0, 1.0]]),
+          "singular": np.array([[1.0, 2, 3], [2, 4, 6], [0, 0, 1]]), "nan": np.array([[1.0, 0, np.nan], [0, 1, 0], [0, 0, 1]]),
+          "persp": np.array([[0.9, 0.2, 1.0], [-0.15, 1.1, 3.0], [3e-3, -2e-3, 1.0]])}
+    cases = []
+    for hn, H in Hm.items():
+        for conv in ("nn", "bilinear"):
+            cases.append(("wp_%s_%s" % (hn, conv), "wrapPerspective", img, dict(H=H, convert=conv)))
+        cases.append(("tih_%s" % hn, "transformImageH", img, dict(H=H)))
+    for hn in ("identity", "mild", "halfshift"):
+        for conv in ("nn", "bilinear"):
+            for res in ((9, 11), (5, 7), (12, 14)):
+                cases.append(("scan_%s_%s_%dx%d" % (hn, conv, res[0], res[1]), "wrapPerspectiveScan", img, dict(H=Hm[hn], res=res, convert=conv)))
+    for conv in ("nn", "bilinear"):
+        cases.append(("tiny_mild_%s" % conv, "wrapPerspective", tiny, dict(H=Hs, convert=conv)))
+        cases.append(("tiny_half_%s" % conv, "wrapPerspective", tiny, dict(H=Hm["halfshift"], convert=conv)))
+        cases.append(("three_mild_%s" % conv, "wrapPerspective", three, dict(H=Hs, convert=conv)))
+    # transformImage(img, u, v, box): u / v = 3 x 4 corner lists (app.py:351-356), box = the scan resolution or None
+    u = np.array([[1.0, 9.0, 8.5, 1.5], [1.0, 1.5, 7.0, 6.5], [1, 1, 1, 1]])
+    v = np.array([[0.0, 7, 7, 0], [0.0, 0, 5, 5], [1, 1, 1, 1]])
+    corners = np.array([[0.0, 10, 10, 0], [0.0, 0, 8, 8], [1, 1, 1, 1]])
+    cases.append(("ti_quad_scan", "transformImage", img, dict(u=u, v=v, box=(6, 8))))
+    cases.append(("ti_quad_auto", "transformImage", img, dict(u=u, v=v)))
+    cases.append(("ti_quad_nn", "transformImage", img, dict(u=u, v=v, box=(6, 8), method="nn")))
+    cases.append(("ti_corners_scan", "transformImage", img, dict(u=corners, v=corners, box=(9, 11))))
+    cases.append(("ti_corners_auto", "transformImage", img, dict(u=corners, v=corners)))
+    return cases
+
+
+def g15():
+    """What the reference's warp entry points do at the corners of their input space: the output array, or the TYPE of the
+    exception -- bilinear indexes texel x + 1, so a coordinate exactly on the last column / row (identity, integer shifts, pure
+    scales, rot90) raises IndexError; a scan `res` beyond the image lets coordinates past it through; a singular H fails in
+    np.linalg.inv; a NaN entry fails in int(); 2 x 2 images work."""
+    out = {"numpy_version": np.array(np.__version__)}
+    names = []
+    for name, fn, img, kw in warp_edge_cases():
+        names.append(name)
+        out[name + "_fn"] = np.array(fn); out[name + "_img"] = img
+        for k_, v in kw.items():
+            out[name + "_arg_" + k_] = np.asarray(v) if not isinstance(v, str) else np.array(v)
+        try:
+            with np.errstate(all="ignore"):
+                r = getattr(ref_h, fn)(img.copy(), **kw)
+            arr = r[0] if isinstance(r, tuple) else r
+            out[name + "_outcome"] = np.array("ok")
+            out[name + "_out"] = np.asarray(arr)
+            if isinstance(r, tuple):
+                out[name + "_origin"] = np.array([r[1], r[2]], dtype=np.int64)
+        except Exception as e:      # noqa: BLE001 -- the type is the datum
+            out[name + "_outcome"] = np.array(type(e).__name__)
+        print(name, str(out[name + "_outcome"]), out.get(name + "_out", np.zeros(0)).shape)
+    out["names"] = np.array(names)
+    save("g15_warp_edge_cases", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -520,6 +585,7 @@ def main():
     if "g12" in which: g12()
     if "g13" in which: g13(ptsA, ptsB)
     if "g14" in which: g14()
+    if "g15" in which: g15()
 
 
 if __name__ == "__main__":

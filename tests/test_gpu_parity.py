@@ -1775,6 +1775,33 @@ def test_ransac_run_random_problem_families_vs_oracle(gpu):
             assert res[0] == res[1], (case, kind, M, th, d, k, n, m, seed, res[0][:2], res[1][:2])
 
 
+def test_warp_entry_points_edge_cases_vs_reference(gpu, auto_mode):
+    """g15 (written by the unmodified reference): the warp entry points at the corners of their input space, numpy arrays in (the
+    reference's own callers) -- the same array bit for bit, dtype and origin, or the same exception TYPE: bilinear on a coordinate
+    exactly ON the last column / row (identity, integer shifts, pure scales, rot90, mirrors) indexes one past the image in the
+    reference (IndexError: `rwh_warp_index_check` finds those), a scan `res` beyond the image, a singular H (LinAlgError), a NaN
+    entry (ValueError), 2 x 2 and 3 x 3 images, transformImage with and without a box."""
+    import homography as hg
+    from test_oracle_golden import _g15_call
+    g = load_golden("g15_warp_edge_cases")
+    fns = {"wrapPerspective": hg.wrapPerspective, "wrapPerspectiveScan": hg.wrapPerspectiveScan,
+           "transformImage": hg.transformImage, "transformImageH": hg.transformImageH}
+    for name in [str(n) for n in g["names"]]:
+        want = str(g[name + "_outcome"])
+        try:
+            with np.errstate(all="ignore"):
+                r = _g15_call(fns, g, name)
+            got = "ok"
+        except Exception as e:      # noqa: BLE001 -- the type is what is compared
+            got = type(e).__name__
+        assert got == want, (name, got, want)
+        if want == "ok":
+            arr = r[0] if isinstance(r, tuple) else r
+            assert arr.dtype == g[name + "_out"].dtype and np.array_equal(arr, g[name + "_out"]), name
+            if isinstance(r, tuple):
+                assert [int(r[1]), int(r[2])] == g[name + "_origin"].tolist(), name
+
+
 def test_ransac_run_edge_cases_vs_reference(gpu):
     """g14 (written by the unmodified reference): the corners of RANSAC.run's input space -- one to four correspondences, none,
     k = 0 / 1, thresholds of 0, below 0 and huge, d of 0 and beyond the number of points, n < 4 and n > M, all points equal,

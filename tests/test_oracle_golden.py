@@ -222,3 +222,40 @@ def test_oracle_ransac_edge_cases_g14():
             if want == "ok":
                 assert int(cnt) == int(g[key + "_count"]) and np.array_equal(inl[0], g[key + "_inliers"]), key
                 assert np.allclose(H, g[key + "_H"], rtol=1e-6, atol=1e-9, equal_nan=True), key
+
+
+def _g15_call(mod_fns, g, name):
+    """Run case `name` of g15 through a module's (wrapPerspective, wrapPerspectiveScan, transformImage, transformImageH)."""
+    fn = str(g[name + "_fn"])
+    img = g[name + "_img"].copy()
+    kw = {}
+    for key in g.files:
+        if key.startswith(name + "_arg_"):
+            v = g[key]
+            k_ = key[len(name) + 5:]
+            kw[k_] = str(v) if v.dtype.kind in "US" else (tuple(int(t) for t in v) if k_ in ("res", "box") else v)
+    return mod_fns[fn](img, **kw)
+
+
+def test_oracle_warp_edge_cases_g15():
+    """g15: what the unmodified reference's warp entry points do at the corners of their input space -- bilinear on a coordinate
+    exactly ON the last column / row (identity, integer shifts, pure scales, rot90, mirrors: IndexError), a scan `res` beyond the
+    image (IndexError), a singular H (LinAlgError), a NaN entry (ValueError), 2 x 2 and 3 x 3 images, transformImage with and
+    without a box: the oracle returns the same array bit for bit or raises the same exception type."""
+    g = load_golden("g15_warp_edge_cases")
+    fns = {"wrapPerspective": orc.wrap_perspective, "wrapPerspectiveScan": orc.wrap_perspective_scan,
+           "transformImage": orc.transform_image, "transformImageH": orc.transform_image_h}
+    for name in [str(n) for n in g["names"]]:
+        want = str(g[name + "_outcome"])
+        try:
+            with np.errstate(all="ignore"):
+                r = _g15_call(fns, g, name)
+            got = "ok"
+        except Exception as e:      # noqa: BLE001 -- the type is what is compared
+            got = type(e).__name__
+        assert got == want, (name, got, want)
+        if want == "ok":
+            arr = r[0] if isinstance(r, tuple) else r
+            assert arr.dtype == g[name + "_out"].dtype and np.array_equal(arr, g[name + "_out"]), name
+            if isinstance(r, tuple):
+                assert [int(r[1]), int(r[2])] == g[name + "_origin"].tolist(), name
