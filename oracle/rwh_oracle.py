@@ -255,6 +255,15 @@ def add_alpha_rate(img, rate=0.2):
     return out
 
 
+def add_alpha_zero(img):
+    """homography.py:250-267 with a `method` that is neither 'Rate' nor 'Gradient' (stitchPanorama passes its `blending`
+    argument through, homography.py:298: e.g. True): the alpha plane is never written and stays 0."""
+    h, w, c = img.shape
+    out = np.zeros((h, w, c + 1), dtype=np.float32)
+    out[:, :, :c] = img
+    return out
+
+
 def add_alpha_gradient(img):
     """homography.py:250-266, method 'Gradient', direction LEFT, alphaOnly False:
     the alpha plane is the float64 ramp (x + y) / (w + h) * 0.5 stored as float32."""
@@ -293,8 +302,10 @@ def stitch_panorama(imgQ, imgT, H, blending=False, blendrate=0.2):
     overlap in float32, otherwise imgQ is pasted over the warped imgT."""
     if blending == 'Gradient':
         imgT = add_alpha_gradient(imgT)
-    elif blending:
+    elif blending == 'Rate':
         imgT = add_alpha_rate(imgT, blendrate)
+    elif blending:
+        imgT = add_alpha_zero(imgT)
     img_t, mx, my = transform_image_h(imgT, H)
     ht, wt, ct = img_t.shape
     hq, wq, _ = imgQ.shape

@@ -569,8 +569,46 @@ def g15():
     save("g15_warp_edge_cases", **out)
 
 
+def g16():
+    """stitchPanorama on small images for every branch of its canvas geometry (homography.py:303-321: the warped image to the
+    left / right of and above / below the query image, inside it, covering it) and every `blending` value the reference's code
+    distinguishes (False, 'Rate', 'Gradient', another truthy value), plus the identity (IndexError from the bilinear warp)."""
+    import contextlib
+    import io
+    rng = np.random.default_rng(16)
+    Q = rng.integers(1, 256, (20, 30, 3), dtype=np.uint8)
+    T = rng.integers(1, 256, (18, 26, 3), dtype=np.uint8)
+    big = rng.integers(1, 256, (40, 52, 3), dtype=np.uint8)
+    P = np.array([[1.0, 0.01, 0], [0.012, 0.99, 0], [2e-4, 1e-4, 1.0]])
+
+    def shift(tx, ty):
+        S = np.eye(3); S[0, 2] = tx; S[1, 2] = ty
+        return S @ P
+    Hm = {"left_up": shift(-7.3, -5.6), "left_down": shift(-9.2, 6.4), "right_up": shift(11.5, -4.3), "right_down": shift(13.7, 8.2),
+          "inside": shift(2.4, 1.3), "far_right": shift(45.2, 3.1), "far_up": shift(3.3, -31.7), "identity": np.eye(3)}
+    out = {"numpy_version": np.array(np.__version__), "Q": Q, "T": T, "big": big}
+    names = []
+    for hn, H in Hm.items():
+        for bn, blending in (("paste", False), ("rate", "Rate"), ("grad", "Gradient"), ("true", True)):
+            for tn, timg in (("T", T), ("big", big)):
+                if tn == "big" and hn not in ("left_up", "inside"):
+                    continue
+                name = "%s_%s_%s" % (hn, bn, tn)
+                names.append(name)
+                out[name + "_H"] = H
+                try:
+                    with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                        r = ref_h.stitchPanorama(Q.copy(), timg.copy(), H, blending=blending, blendrate=0.35)
+                    out[name + "_outcome"] = np.array("ok"); out[name + "_out"] = np.asarray(r)
+                except Exception as e:      # noqa: BLE001 -- the type is the datum
+                    out[name + "_outcome"] = np.array(type(e).__name__)
+                print(name, str(out[name + "_outcome"]), out.get(name + "_out", np.zeros(0)).shape)
+    out["names"] = np.array(names)
+    save("g16_stitch_geometry", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -586,6 +624,7 @@ def main():
     if "g13" in which: g13(ptsA, ptsB)
     if "g14" in which: g14()
     if "g15" in which: g15()
+    if "g16" in which: g16()
 
 
 if __name__ == "__main__":

@@ -1802,6 +1802,28 @@ def test_warp_entry_points_edge_cases_vs_reference(gpu, auto_mode):
                 assert [int(r[1]), int(r[2])] == g[name + "_origin"].tolist(), name
 
 
+def test_stitch_geometry_and_blending_vs_reference(gpu, auto_mode):
+    """g16 (written by the unmodified reference): stitchPanorama on small images for every branch of its canvas geometry, every
+    `blending` value its code distinguishes (False, 'Rate', 'Gradient', another truthy value -- an all-zero alpha plane) and the
+    identity homography (IndexError from the bilinear warp of imgT): numpy arrays in, the same canvas bit for bit or the same
+    exception type."""
+    import contextlib
+    import io
+    import homography as hg
+    from test_oracle_golden import _g16_cases
+    g = load_golden("g16_stitch_geometry")
+    for name, Q, T, H, blending, want in _g16_cases(g):
+        try:
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                r = hg.stitchPanorama(Q, T, H, blending=blending, blendrate=0.35)
+            got = "ok"
+        except Exception as e:      # noqa: BLE001 -- the type is what is compared
+            got = type(e).__name__
+        assert got == want, (name, got, want)
+        if want == "ok":
+            assert r.dtype == g[name + "_out"].dtype and np.array_equal(r, g[name + "_out"]), (name, r.shape, g[name + "_out"].shape)
+
+
 def test_ransac_run_edge_cases_vs_reference(gpu):
     """g14 (written by the unmodified reference): the corners of RANSAC.run's input space -- one to four correspondences, none,
     k = 0 / 1, thresholds of 0, below 0 and huge, d of 0 and beyond the number of points, n < 4 and n > M, all points equal,

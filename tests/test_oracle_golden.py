@@ -259,3 +259,29 @@ def test_oracle_warp_edge_cases_g15():
             assert arr.dtype == g[name + "_out"].dtype and np.array_equal(arr, g[name + "_out"]), name
             if isinstance(r, tuple):
                 assert [int(r[1]), int(r[2])] == g[name + "_origin"].tolist(), name
+
+
+def _g16_cases(g):
+    for name in [str(n) for n in g["names"]]:
+        hn, bn, tn = name.rsplit("_", 2)
+        blending = {"paste": False, "rate": "Rate", "grad": "Gradient", "true": True}[bn]
+        yield name, g["Q"].copy(), g[tn].copy(), g[name + "_H"], blending, str(g[name + "_outcome"])
+
+
+def test_oracle_stitch_geometry_g16():
+    """g16: stitchPanorama of the unmodified reference on small images for every branch of its canvas geometry (the warped image
+    left / right of, above / below, inside and around the query image), every `blending` value its code distinguishes, and the
+    identity (IndexError from the bilinear warp): the oracle's canvas is the same array, or it raises the same exception type."""
+    import contextlib
+    import io
+    g = load_golden("g16_stitch_geometry")
+    for name, Q, T, H, blending, want in _g16_cases(g):
+        try:
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                r = orc.stitch_panorama(Q, T, H, blending=blending, blendrate=0.35)
+            got = "ok"
+        except Exception as e:      # noqa: BLE001 -- the type is what is compared
+            got = type(e).__name__
+        assert got == want, (name, got, want)
+        if want == "ok":
+            assert r.dtype == g[name + "_out"].dtype and np.array_equal(r, g[name + "_out"]), name
