@@ -270,8 +270,17 @@ class HomoModel(Model):
             x[:2, :] = P
         else:
             x = P
+        if m < 2:
+            # no point: numpy's empty product.  ONE point: numpy hands a 3 x 3 by 3 x 1 product to BLAS's matrix-VECTOR routine,
+            # whose sums round differently from the matrix-matrix routine every other width takes (and the kernels reproduce):
+            # the reference's own expression on the host (ransac.py:63-64 / 74-76), nine multiply-adds
+            h = np.linalg.inv(val) if inverse else val
+            y = h @ x
+            return y / (y[-1, :] + 1e-10)
         if val.dtype == np.float32 and x.dtype == np.float32 and nrow == 2:
             # the RANSAC loop's own case: float32 H, w == 1, inverse by the kernel's float64 LU (bit-identical to numpy's)
+            if inverse:
+                np.linalg.inv(val)                        # (for its LinAlgError on a singular val, ransac.py:74)
             h9 = torch.from_numpy(np.ascontiguousarray(val).reshape(9)).to(dev)
             pts = torch.from_numpy(np.ascontiguousarray(x[:2].T)).to(dev)
             return kernels.project_points(h9, pts, inverse).cpu().numpy()
@@ -303,8 +312,10 @@ class HomoModel(Model):
         import torch
         if method not in _lib.RWH_LOSS:
             exit("Invalid method!")  # ransac.py:97
+        if method != "fwd":
+            np.linalg.inv(self.val)                       # ransac.py:74 raises LinAlgError on a singular val
         if np.asarray(self.val).dtype != np.float32 or np.asarray(X).dtype != np.float32 or np.asarray(Y).dtype != np.float32 \
-                or X.shape[0] != 2 or Y.shape[0] != 2:
+                or X.shape[0] != 2 or Y.shape[0] != 2 or X.shape[1] < 2:
             # not the RANSAC loop's float32 case (e.g. model.val is the float64 refit after run()): numpy computes these in
             # float64 -- the reference's own composition of fwd / reproj / dist (ransac.py:84-96), projections on the GPU
             err = None

@@ -607,8 +607,71 @@ def g16():
     save("g16_stitch_geometry", **out)
 
 
+def model_cases(ptsA, ptsB):
+    """Inputs of g17: (name, val or None, op, args) for HomoModel's helpers at the corners of their input space."""
+    rng = np.random.default_rng(17)
+    A, B = ptsA[:40], ptsB[:40]
+    m = ref_r.HomoModel(th=5, d=50, n=4)
+    v32 = np.asarray(m.fit(A[:4].T, B[:4].T), dtype=np.float32)
+    m6 = ref_r.HomoModel(th=5, d=50, n=4)
+    v64 = np.asarray(m6.fit(A[:9].T, B[:9].T, collective=True))
+    vals = {"v32": v32, "v64": v64, "zerorow": np.array([[1, 0, 2], [0, 1, 3], [0, 0, 0]], np.float32),
+            "singular": np.array([[1, 2, 3], [2, 4, 6], [0, 0, 1]], np.float32), "nanval": np.array([[1, 0, np.nan], [0, 1, 0], [0, 0, 1]], np.float32)}
+    X2, Y2 = A.T.copy(), B.T.copy()                                            # 2 x 40 float32
+    X3 = np.vstack([X2, rng.uniform(0.5, 2.0, (1, 40)).astype(np.float32)])    # third row is NOT 1
+    Y3 = np.vstack([Y2, np.ones((1, 40), np.float32)])
+    inputs = {"x2": X2, "x3": X3, "x2f64": X2.astype(np.float64), "x3f64": X3.astype(np.float64), "x2int": X2.astype(np.int32),
+              "empty2": np.zeros((2, 0), np.float32), "one2": X2[:, :1].copy(), "x4rows": np.vstack([X3, X3[:1]]), "x1row": X2[:1].copy()}
+    cases = []
+    for vn, val in vals.items():
+        for xn in (("x2", "x3", "x2f64", "x3f64", "x2int", "empty2", "one2", "x4rows", "x1row") if vn == "v32" else ("x2", "x3", "x3f64")):
+            cases.append(("fwd_%s_%s" % (vn, xn), val, "fwd", (inputs[xn],)))
+            cases.append(("reproj_%s_%s" % (vn, xn), val, "reproj", (inputs[xn],)))
+        for meth in ("fwd", "backward", "reproj", "nonsense"):
+            cases.append(("loss_%s_%s" % (vn, meth), val, "computeLoss", (X2, Y2, meth)))
+    cases.append(("loss_v32_x3y3", v32, "computeLoss", (X3, Y3, "fwd")))
+    cases.append(("loss_v32_x3y2_reproj", v32, "computeLoss", (X3, Y2, "reproj")))
+    cases.append(("loss_v32_f64", v32, "computeLoss", (X2.astype(np.float64), Y2.astype(np.float64), "reproj")))
+    cases.append(("dist_basic", v32, "dist", (X2, Y2)))
+    cases.append(("dist_shape", v32, "dist", (X3, Y2)))
+    for name, xa, ya, coll in (("fit_2x4", X2[:, :4], Y2[:, :4], False), ("fit_3x4", X3[:, :4], Y3[:, :4], False), ("fit_2x5", X2[:, :5], Y2[:, :5], False),
+                               ("fit_2x9_coll", X2[:, :9], Y2[:, :9], True), ("fit_3x9_coll", X3[:, :9], Y3[:, :9], True), ("fit_2x4_coll", X2[:, :4], Y2[:, :4], True),
+                               ("fit_2x3", X2[:, :3], Y2[:, :3], False), ("fit_mixed_rows", X3[:, :4], Y2[:, :4], False), ("fit_1row", X2[:1, :4], Y2[:1, :4], False),
+                               ("fit_repeated", X2[:, [0, 1, 1, 2]], Y2[:, [0, 1, 1, 2]], False), ("fit_f64", X2[:, :4].astype(np.float64), Y2[:, :4].astype(np.float64), False)):
+        cases.append((name, None, "fit", (xa, ya, coll)))
+    return cases
+
+
+def g17(ptsA, ptsB):
+    """HomoModel's helpers (ransac.py:30-98) at the corners of their input space: float32 / float64 `val`, a zero bottom row, a
+    singular and a NaN `val`; 2- and 3-row inputs whose third row is kept, float64 and integer inputs, no point, one point,
+    wrong row counts; every `method` of computeLoss and an unknown one (SystemExit); fit on 2- / 3-row samples, collective
+    refits, wrong sizes, a repeated point.  The returned array (values AND dtype) or the exception type."""
+    import contextlib
+    import io
+    out = {"numpy_version": np.array(np.__version__)}
+    names = []
+    for name, val, op, args in model_cases(ptsA, ptsB):
+        names.append(name)
+        out[name + "_op"] = np.array(op)
+        if val is not None: out[name + "_val"] = val
+        for i, a in enumerate(args):
+            out[name + "_a%d" % i] = np.array(a) if isinstance(a, (str, bool)) else a
+        m = ref_r.HomoModel(th=5, d=50, n=4)
+        if val is not None: m.val = val.copy()
+        try:
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                r = getattr(m, op)(*[a.copy() if isinstance(a, np.ndarray) else a for a in args])
+            out[name + "_outcome"] = np.array("ok"); out[name + "_out"] = np.asarray(r)
+        except BaseException as e:      # noqa: BLE001 -- SystemExit included: the type is the datum
+            out[name + "_outcome"] = np.array(type(e).__name__)
+        print(name, str(out[name + "_outcome"]), getattr(out.get(name + "_out"), "dtype", ""), getattr(out.get(name + "_out"), "shape", ""))
+    out["names"] = np.array(names)
+    save("g17_model_helpers", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -625,6 +688,7 @@ def main():
     if "g14" in which: g14()
     if "g15" in which: g15()
     if "g16" in which: g16()
+    if "g17" in which: g17(ptsA, ptsB)
 
 
 if __name__ == "__main__":

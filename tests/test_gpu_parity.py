@@ -1824,6 +1824,37 @@ def test_stitch_geometry_and_blending_vs_reference(gpu, auto_mode):
             assert r.dtype == g[name + "_out"].dtype and np.array_equal(r, g[name + "_out"]), (name, r.shape, g[name + "_out"].shape)
 
 
+def test_model_helpers_edge_cases_vs_reference(gpu):
+    """g17 (written by the unmodified reference): HomoModel.fwd / reproj / dist / computeLoss / fit at the corners of their input
+    space -- float32 and float64 `val`, a zero bottom row, a singular and a NaN `val`; 2- and 3-row inputs whose third row is kept,
+    float64 and integer inputs, no point, one point, wrong row counts (AssertionError); every `method` and an unknown one
+    (SystemExit); fits on 2- / 3-row samples, collective refits, wrong sizes, a repeated point: the same array -- values bit for
+    bit AND dtype -- or the same exception type."""
+    import contextlib
+    import io
+    import ransac as rs
+    from test_oracle_golden import _g17_cases, _same_array
+    g = load_golden("g17_model_helpers")
+    wrong = []
+    for name, op, val, args, want in _g17_cases(g):
+        m = rs.HomoModel(th=5, d=50, n=4)
+        if val is not None:
+            m.val = val
+        try:
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                r = getattr(m, op)(*args)
+            got = "ok"
+        except BaseException as e:      # noqa: BLE001 -- SystemExit included
+            got = type(e).__name__
+        if got != want:
+            wrong.append((name, got, want))
+        elif want == "ok" and not _same_array(r, g[name + "_out"]):
+            ra = np.asarray(r)
+            wrong.append((name, str(ra.dtype), str(g[name + "_out"].dtype), ra.shape,
+                          int((ra != g[name + "_out"]).sum()) if ra.shape == g[name + "_out"].shape else -1))
+    assert not wrong, wrong
+
+
 def test_ransac_run_edge_cases_vs_reference(gpu):
     """g14 (written by the unmodified reference): the corners of RANSAC.run's input space -- one to four correspondences, none,
     k = 0 / 1, thresholds of 0, below 0 and huge, d of 0 and beyond the number of points, n < 4 and n > M, all points equal,

@@ -285,3 +285,44 @@ def test_oracle_stitch_geometry_g16():
         assert got == want, (name, got, want)
         if want == "ok":
             assert r.dtype == g[name + "_out"].dtype and np.array_equal(r, g[name + "_out"]), name
+
+
+def _g17_cases(g):
+    for name in [str(n) for n in g["names"]]:
+        args = []
+        i = 0
+        while name + "_a%d" % i in g.files:
+            a = g[name + "_a%d" % i]
+            args.append(str(a) if a.dtype.kind in "US" else bool(a) if a.dtype == np.bool_ and a.ndim == 0 else a.copy())
+            i += 1
+        yield name, str(g[name + "_op"]), (g[name + "_val"].copy() if name + "_val" in g.files else None), args, str(g[name + "_outcome"])
+
+
+def _same_array(got, want):
+    got = np.asarray(got)
+    return got.dtype == want.dtype and got.shape == want.shape and np.array_equal(got, want, equal_nan=True)
+
+
+def test_oracle_model_helpers_g17():
+    """g17: HomoModel.fwd / reproj / dist / computeLoss / fit of the unmodified reference at the corners of their input space
+    (float32 and float64 `val`, zero bottom row, singular, NaN; 2- and 3-row inputs, float64 and integer inputs, no point, one
+    point; every method and an unknown one; collective refits, a repeated point): the oracle's functions return the same array,
+    values and dtype, or fail the same way.  (The reference's input assertions live in its class, not in the oracle's free
+    functions: those cases are the product's to reproduce, tests/test_gpu_parity.py.)"""
+    g = load_golden("g17_model_helpers")
+    for name, op, val, args, want in _g17_cases(g):
+        if want == "AssertionError":
+            continue
+        try:
+            with np.errstate(all="ignore"):
+                if op == "fwd": r = orc.project_fwd(val, *args)
+                elif op == "reproj": r = orc.project_back(val, *args)
+                elif op == "dist": r = orc.l2_dist(*args)
+                elif op == "computeLoss": r = orc.compute_loss(val, *args)
+                else: r = orc.fit_all(args[0], args[1]) if args[2] else orc.fit_minimal(args[0], args[1])
+            got = "ok"
+        except BaseException as e:      # noqa: BLE001 -- SystemExit included
+            got = type(e).__name__
+        assert got == want, (name, got, want)
+        if want == "ok":
+            assert _same_array(r, g[name + "_out"]), (name, np.asarray(r).dtype, g[name + "_out"].dtype)
