@@ -74,14 +74,24 @@ def _pair_rows(u, v, sign):
     return a.reshape(2 * n, 8), b.reshape(2 * n, 1)
 
 
+def _four_rows(u, v):
+    """The 4-point builders index rows 0..3 of both arrays by hand (homography.py:6-13, 18-27): with fewer rows they fail at
+    the first index that is not there."""
+    u, v = np.asarray(u), np.asarray(v)
+    for a in (u, v):
+        if a.shape[0] < 4:
+            raise IndexError("index %d is out of bounds for axis 0 with size %d" % (a.shape[0], a.shape[0]))
+    return u[:4], v[:4]
+
+
 def calc_corresp(u, v):
     """8 x 9 DLT matrix of 4 pairs, float32 (homography.py:4-14)."""
-    return _pair_rows(np.asarray(u)[:4], np.asarray(v)[:4], -1)
+    return _pair_rows(*_four_rows(u, v), -1)
 
 
 def calc_correspLinear(u, v):
     """(8 x 8 A, 8 x 1 b), float32 (homography.py:16-28)."""
-    return _pair_rows(np.asarray(u)[:4], np.asarray(v)[:4], +1)
+    return _pair_rows(*_four_rows(u, v), +1)
 
 
 def calc_correspCollective(u, v):

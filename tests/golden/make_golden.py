@@ -670,8 +670,92 @@ def g17(ptsA, ptsB):
     save("g17_model_helpers", **out)
 
 
+def host_cases(ptsA, ptsB):
+    """Inputs of g18: (name, function, args, kwargs) for the host-side builders / solvers, addAlpha and the two interpolators on
+    caller-computed coordinates."""
+    rng = np.random.default_rng(18)
+    A, B = ptsA[:12].copy(), ptsB[:12].copy()
+    cases = []
+    for tag, u, v in (("f32", A, B), ("f64", A.astype(np.float64), B.astype(np.float64)), ("int", A.astype(np.int32), B.astype(np.int32)),
+                      ("big", A * 1e4, B * 1e4), ("same", np.tile(A[:1], (12, 1)), np.tile(B[:1], (12, 1))),
+                      ("collinear", np.stack([np.arange(12.0), 2 * np.arange(12.0)], 1).astype(np.float32), B)):
+        for fn in ("calc_corresp", "calc_correspLinear"):
+            cases.append(("%s_%s" % (fn, tag), fn, (u[:4], v[:4]), {}))
+        for fn in ("calc_correspCollective", "calc_correspLinearCollective"):
+            cases.append(("%s_%s" % (fn, tag), fn, (u, v), {}))
+        for fn in ("calcHomography", "calcHomographyLinear"):
+            cases.append(("%s_%s" % (fn, tag), fn, (u[:4], v[:4]), {}))
+            cases.append(("%s_%s_coll" % (fn, tag), fn, (u, v), {"collective": True}))
+    cases.append(("calcHomography_3pts", "calcHomography", (A[:3], B[:3]), {}))
+    cases.append(("calcHomography_5pts_noncoll", "calcHomography", (A[:5], B[:5]), {}))
+    cases.append(("calcHomographyLinear_coll_4", "calcHomographyLinear", (A[:4], B[:4]), {"collective": True}))
+    cases.append(("calcHomographyLinear_coll_3", "calcHomographyLinear", (A[:3], B[:3]), {"collective": True}))
+    cases.append(("calcHomography_nan", "calcHomography", (np.where(np.arange(8).reshape(4, 2) == 3, np.nan, A[:4]).astype(np.float32), B[:4]), {}))
+    img3 = rng.integers(0, 256, (7, 9, 3), dtype=np.uint8)
+    img4 = rng.uniform(0, 255, (7, 9, 4)).astype(np.float32)
+    for meth in ("Rate", "Gradient", "Other"):
+        for ao in (False, True):
+            cases.append(("addAlpha_%s_%d" % (meth, ao), "addAlpha", (img3,), {"method": meth, "rate": 0.3, "alphaOnly": ao}))
+    cases.append(("addAlpha_grad_right", "addAlpha", (img3,), {"method": "Gradient", "direction": ref_h.BLENDDIR.RIGHT, "alphaOnly": True}))
+    cases.append(("addAlpha_grad_top", "addAlpha", (img3,), {"method": "Gradient", "direction": ref_h.BLENDDIR.TOP, "alphaOnly": True}))
+    cases.append(("addAlpha_4ch", "addAlpha", (img4,), {"method": "Rate"}))
+    # interpolators on caller-computed coordinates (3 x N, dehomogenised), mh x mw = 4 x 6
+    base = np.stack([rng.uniform(-1.5, 9.5, 24), rng.uniform(-1.5, 7.5, 24), np.ones(24)])
+    inside = np.stack([rng.uniform(0, 7.9, 24), rng.uniform(0, 5.9, 24), np.ones(24)])
+    edge = inside.copy(); edge[0, 3] = 8.0; edge[1, 5] = 3.0
+    edge_y = inside.copy(); edge_y[1, 7] = 6.0
+    halves = inside.copy(); halves[0, :6] = [0.5, 1.5, 2.5, 7.5, 7.49999, 0.49999]; halves[1, :6] = [0.5, 5.5, 2.5, 3.5, 5.49999, 0.0]
+    nanc = inside.copy(); nanc[0, 2] = np.nan
+    infc = inside.copy(); infc[0, 2] = np.inf; infc[1, 4] = -np.inf
+    neg = inside.copy(); neg[0, 1] = -0.3; neg[1, 2] = -0.7; neg[0, 3] = -1.2
+    for cn, z in (("mixed", base), ("inside", inside), ("edge_x", edge), ("edge_y", edge_y), ("halves", halves), ("nan", nanc), ("inf", infc), ("neg", neg)):
+        for fn in ("nearestNeighbor", "bilinear"):
+            for tn, im in (("u8", img3), ("f32x4", img4)):
+                cases.append(("%s_%s_%s" % (fn, cn, tn), fn, (z, im, 7, 9, 4, 6), {}))
+    for fn in ("nearestNeighbor", "bilinear"):      # a bound (h, w) smaller and larger than the image
+        cases.append(("%s_smallbound" % fn, fn, (inside, img3, 5, 6, 4, 6), {}))
+        cases.append(("%s_bigbound" % fn, fn, (base + 0.0, img3, 12, 14, 4, 6), {}))
+    return cases
+
+
+def g18(ptsA, ptsB):
+    """The host-side builders and solvers (homography.py:4-105), addAlpha (250-286) and the two interpolators on coordinates the
+    caller computed (108-138) at the corners of their input space: float32 / float64 / integer points, huge coordinates, twelve
+    equal points, collinear points, too few points, a NaN coordinate; every addAlpha method, direction and channel count;
+    coordinates inside, outside, exactly on the last column / row, on .5, NaN and Inf, bounds smaller and larger than the image.
+    Returned arrays (values and dtype), what the call did to its arguments (the interpolators blank texel (0,0) and bilinear
+    writes zeros into the caller's coordinates), or the exception type."""
+    import contextlib
+    import io
+    out = {"numpy_version": np.array(np.__version__)}
+    names = []
+    for name, fn, args, kw in host_cases(ptsA, ptsB):
+        names.append(name)
+        out[name + "_fn"] = np.array(fn)
+        for i, a in enumerate(args):
+            out[name + "_a%d" % i] = np.asarray(a)
+        for k_, v in kw.items():
+            out[name + "_kw_" + k_] = np.asarray(v)
+        call = [a.copy() if isinstance(a, np.ndarray) else a for a in args]
+        try:
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                r = getattr(ref_h, fn)(*call, **kw)
+            out[name + "_outcome"] = np.array("ok")
+            for i, part in enumerate(r if isinstance(r, tuple) else (r,)):
+                out[name + "_out%d" % i] = np.asarray(part)
+            for i, (a, c_) in enumerate(zip(args, call)):      # side effects on the arguments
+                if isinstance(a, np.ndarray) and not np.array_equal(a, c_, equal_nan=True):
+                    out[name + "_after%d" % i] = c_
+        except Exception as e:      # noqa: BLE001 -- the type is the datum
+            out[name + "_outcome"] = np.array(type(e).__name__)
+        print(name, str(out[name + "_outcome"]), getattr(out.get(name + "_out0"), "dtype", ""), getattr(out.get(name + "_out0"), "shape", ""),
+              [k_ for k_ in out if k_.startswith(name + "_after")])
+    out["names"] = np.array(names)
+    save("g18_host_helpers", **out)
+
+
 def main():
-    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17"}
+    which = set(sys.argv[1:]) or {"g1", "g2", "g4", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14", "g15", "g16", "g17", "g18"}
     ptsA, ptsB = load_matches()
     save("matchespoints", ptsA=ptsA, ptsB=ptsB)
     if "g1" in which: g1()
@@ -689,6 +773,7 @@ def main():
     if "g15" in which: g15()
     if "g16" in which: g16()
     if "g17" in which: g17(ptsA, ptsB)
+    if "g18" in which: g18(ptsA, ptsB)
 
 
 if __name__ == "__main__":

@@ -1855,6 +1855,33 @@ def test_model_helpers_edge_cases_vs_reference(gpu):
     assert not wrong, wrong
 
 
+def test_host_helpers_and_interpolators_vs_reference(gpu, auto_mode):
+    """g18 (written by the unmodified reference): the module's builders / solvers, addAlpha and the two interpolators on
+    caller-computed coordinates at the corners of their input space -- float32 / float64 / integer points, huge coordinates,
+    equal and collinear points (LinAlgError), too few points (IndexError), a NaN point; every addAlpha method, direction
+    (TOP: UnboundLocalError) and channel count; coordinates inside, outside, exactly on the last column / row (bilinear:
+    IndexError), on .5, NaN (bilinear: IndexError) and Inf, bounds smaller and larger than the image (IndexError): the same
+    arrays bit for bit and in dtype, the same side effects on the arguments, or the same exception type."""
+    import contextlib
+    import io
+    import homography as hg
+    from test_oracle_golden import _g18_cases, _g18_check
+    g = load_golden("g18_host_helpers")
+    wrong = []
+    for name, fn, args, kw, want, outs, after in _g18_cases(g):
+        try:
+            with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                r = getattr(hg, fn)(*args, **kw)
+            got = "ok"
+        except Exception as e:      # noqa: BLE001 -- the type is what is compared
+            got = type(e).__name__
+        if got != want:
+            wrong.append((name, got, want))
+        elif want == "ok":
+            _g18_check(name, r, args, outs, after, wrong)
+    assert not wrong, wrong
+
+
 def test_ransac_run_edge_cases_vs_reference(gpu):
     """g14 (written by the unmodified reference): the corners of RANSAC.run's input space -- one to four correspondences, none,
     k = 0 / 1, thresholds of 0, below 0 and huge, d of 0 and beyond the number of points, n < 4 and n > M, all points equal,

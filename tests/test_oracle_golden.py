@@ -326,3 +326,60 @@ def test_oracle_model_helpers_g17():
         assert got == want, (name, got, want)
         if want == "ok":
             assert _same_array(r, g[name + "_out"]), (name, np.asarray(r).dtype, g[name + "_out"].dtype)
+
+
+def _g18_cases(g):
+    for name in [str(n) for n in g["names"]]:
+        args, i = [], 0
+        while name + "_a%d" % i in g.files:
+            a = g[name + "_a%d" % i]
+            args.append(a.copy() if a.ndim else a.item())
+            i += 1
+        kw = {}
+        for key in g.files:
+            if key.startswith(name + "_kw_"):
+                v = g[key]
+                kw[key[len(name) + 4:]] = str(v) if v.dtype.kind in "US" else v.item()
+        outs, i = [], 0
+        while name + "_out%d" % i in g.files:
+            outs.append(g[name + "_out%d" % i]); i += 1
+        after = {j: g[name + "_after%d" % j] for j in range(len(args)) if name + "_after%d" % j in g.files}
+        yield name, str(g[name + "_fn"]), args, kw, str(g[name + "_outcome"]), outs, after
+
+
+def _g18_check(name, r, args, outs, after, wrong):
+    parts = r if isinstance(r, tuple) else (r,)
+    if len(parts) != len(outs) or not all(_same_array(p_, o) for p_, o in zip(parts, outs)):
+        wrong.append((name, "result", [str(np.asarray(p_).dtype) for p_ in parts], [str(o.dtype) for o in outs]))
+    for j, a in enumerate(args):            # what the call did to its arguments
+        if isinstance(a, np.ndarray):
+            want = after.get(j)
+            if want is not None and not np.array_equal(a, want, equal_nan=True):
+                wrong.append((name, "argument %d after the call" % j))
+
+
+def test_oracle_host_helpers_and_interpolators_g18(matches):
+    """g18: the reference's builders / solvers (homography.py:4-105) and its two interpolators on caller-computed coordinates
+    (108-138) at the corners of their input space: the oracle returns the same arrays (values and dtype), leaves its arguments
+    as the reference leaves them (texel (0,0) blanked; bilinear zeroes the masked coordinates in the caller's array), or raises
+    the same exception type.  (addAlpha's variants and the fixed 4-row builders' IndexError are the product's to reproduce.)"""
+    g = load_golden("g18_host_helpers")
+    table = {"calc_corresp": lambda u, v: orc.dlt_matrix(u, v), "calc_correspCollective": lambda u, v: orc.dlt_matrix(u, v),
+             "calc_correspLinear": lambda u, v: orc.linear_system(u, v), "calc_correspLinearCollective": lambda u, v: orc.linear_system(u, v),
+             "calcHomography": orc.calc_homography, "calcHomographyLinear": orc.calc_homography_linear,
+             "nearestNeighbor": orc.nearest_neighbor, "bilinear": orc.bilinear}
+    wrong = []
+    for name, fn, args, kw, want, outs, after in _g18_cases(g):
+        if fn not in table or name in ("calcHomography_3pts",):
+            continue
+        try:
+            with np.errstate(all="ignore"):
+                r = table[fn](*args, **kw)
+            got = "ok"
+        except Exception as e:      # noqa: BLE001 -- the type is what is compared
+            got = type(e).__name__
+        if got != want:
+            wrong.append((name, got, want))
+        elif want == "ok":
+            _g18_check(name, r, args, outs, after, wrong)
+    assert not wrong, wrong
