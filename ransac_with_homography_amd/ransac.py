@@ -29,7 +29,14 @@ arithmetic (float32 DLT matrix -> LAPACK dgesdd, the routine numpy.linalg.svd ca
 every flagged hypothesis and every unflagged one whose count is within a margin of the best (or of the
 early-exit count), re-scores those rows with K2 (bit-exact given H) and only then applies the accept rules.
 The repeated-index samples are known before anything is launched: `presettle` solves them on the host
-while the GPU searches.  k = 1500 at M = 185: ~90 host solves in two batches, 0.8 ms per run end to end.
+while the GPU searches; the whole driver is one native call (`rwh_ransac_run`).  k = 1500 at M = 185: ~90 host solves,
+0.36-0.42 ms per run end to end.
+
+Error behaviour (fixture g14, written by the unmodified reference): k = 0 raises UnboundLocalError (ransac.py:203 reads a
+variable only the loop assigns), a run in which no hypothesis has an inlier indexes with np.where(None) (an error from numpy
+2.1 on), n < 4 raises IndexError after the first draw, a sample holding a NaN coordinate raises LinAlgError at ITS iteration
+unless an earlier one took the early exit, a winner with fewer inliers than the refit accepts fails the refit's assertion --
+each with numpy's generator left where the reference leaves it.
 
 There is no CPU implementation of the loop here: without librwh_hip.so and a GPU
 `RANSAC.run` raises `RwhUnavailable`.
