@@ -213,6 +213,18 @@ RWH_API int rwh_score_count(const float* d_h, const float* d_pts_a, const float*
                     int32_t* d_counts, uint64_t* d_masks, uint64_t* d_best, float* d_err, void* stream);
 
 /*
+ * The same with the INVERSE of every hypothesis supplied by the caller (d_hinv: K x 9 float32, row-major; NULL = as above).
+ * 'backward' and 'reproj' project through numpy.linalg.inv(val) (ransac.py:74: float64 LAPACK dgesv on the identity, cast
+ * to float32).  The kernels' own float64 elimination gives the same float32 matrix for every homography a sane sample
+ * produces, but NOT for a nearly singular one (a sample drawn from two or three clusters): there the two round apart, and so
+ * do the losses.  The settle step of RANSAC.run therefore inverts the hypotheses it re-scores with numpy's own routine
+ * (rwh_host_inv3) and scores them through this entry point.
+ */
+RWH_API int rwh_score_count_inv(const float* d_h, const float* d_hinv, const float* d_pts_a, const float* d_pts_b, int m, int k,
+                        double th, int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,
+                        uint64_t* d_best, float* d_err, void* stream);
+
+/*
  * Project M points through one homography.  Replaces HomoModel.fwd (ransac.py:55-64,
  * inverse == 0) and HomoModel.reproj (ransac.py:66-76, inverse != 0: through the
  * float64 inverse rounded to float32).  d_h: 9 float32; d_pts: M x 2 float32;
@@ -290,6 +302,13 @@ RWH_API int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, con
                       void* dgesdd_ilp64, int threads, float* out_h);
 
 /*
+ * HOST helper: n x numpy.linalg.inv of a float32 3 x 3 (ransac.py:74) -- float64 dgesv on the identity, the routine numpy
+ * calls, by address (`scipy_dgesv_64_`), cast back to float32.  h, out: n x 9 float32 HOST arrays, row-major.  A singular
+ * matrix (numpy raises LinAlgError) gives NaNs.
+ */
+RWH_API int rwh_host_inv3(const float* h, int n, void* dgesv_ilp64, float* out);
+
+/*
  * The host driver of RANSAC.run (ransac.py:159-213 up to, not including, the final refit) as ONE native call: upload,
  * rwh_ransac_search, the settle step -- the reference's own solver (rwh_host_dlt4_svd) for every sample K1 flags and every
  * hypothesis whose count is within min(margin_cap, 3 + count / 16) of a decision (the best count, `need`), re-scored by
@@ -304,11 +323,13 @@ RWH_API int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, con
  *   after the settle step (offsets[15]);
  *   out: 6 x int32 = winner index (-1: nothing ever scored > 0), early exit (0 / 1), winner's count, hypotheses solved on the
  *   host, settle rounds, samples flagged by K1;  out_mask: ceil(m / 64) x uint64, the winner's inlier bitmask.
- * Synchronises `stream` (its results are host values).  rwh_ransac_run_layout: fills offsets[0 .. 20), returns 20.
+ *   dgesv_ilp64: address of LAPACK dgesv in the same library (numpy.linalg.inv's routine), or NULL: with it the hypotheses
+ *   the settle step re-scores under 'backward' / 'reproj' are inverted by rwh_host_inv3 (see rwh_score_count_inv).
+ * Synchronises `stream` (its results are host values).  rwh_ransac_run_layout: fills offsets[0 .. 22), returns 22.
  */
 RWH_API int rwh_ransac_run_layout(int m, int k, long long* offsets, int n_offsets);
 RWH_API int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const int32_t* idx, int k, double th, int loss,
-                   int need, int margin_cap, void* dgesdd_ilp64, int threads, void* d_ws, void* h_ws,
+                   int need, int margin_cap, void* dgesdd_ilp64, void* dgesv_ilp64, int threads, void* d_ws, void* h_ws,
                    int32_t* out, uint64_t* out_mask, void* stream);
 
 /*

@@ -10,6 +10,38 @@ import ctypes
 import os
 
 _addr = False
+_addrs = {}
+
+
+def routine_address(routine):
+    """Address of LAPACK `routine` ('dgesdd', 'dgesv': what numpy.linalg.svd / numpy.linalg.inv call) in the ILP64 OpenBLAS numpy
+    has loaded, or None."""
+    if routine in _addrs:
+        return _addrs[routine]
+    _addrs[routine] = None
+    try:
+        import numpy.linalg._umath_linalg  # noqa: F401
+        paths = set()
+        with open("/proc/self/maps") as f:
+            for line in f:
+                p = line.rsplit(" ", 1)[-1].strip()
+                if "openblas" in os.path.basename(p) and "numpy" in p:
+                    paths.add(p)
+        for p in sorted(paths):
+            lib = ctypes.CDLL(p)
+            for name in ("scipy_%s_64_" % routine, "%s_64_" % routine):
+                try:
+                    _addrs[routine] = ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
+                    return _addrs[routine]
+                except AttributeError:
+                    continue
+    except Exception:
+        _addrs[routine] = None
+    return _addrs[routine]
+
+
+def dgesv_address():
+    return routine_address("dgesv")
 
 
 def dgesdd_address():

@@ -25,7 +25,7 @@ RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT = 0, 1, 2
 # every symbol include/rwh.h declares (tests check the library exports them all)
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama",
-           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check")
+           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check", "rwh_score_count_inv", "rwh_host_inv3")
 
 
 class RwhUnavailable(RuntimeError):
@@ -67,6 +67,10 @@ def _bind(lib):
     lib.rwh_dlt4_batched.argtypes = [vp, vp, i32, vp, i32, vp, vp, vp]
     lib.rwh_score_count.restype = i32
     lib.rwh_score_count.argtypes = [vp, vp, vp, i32, i32, f64, i32, i32, i64, vp, vp, vp, vp, vp]
+    lib.rwh_score_count_inv.restype = i32
+    lib.rwh_score_count_inv.argtypes = [vp, vp, vp, vp, i32, i32, f64, i32, i32, i64, vp, vp, vp, vp, vp]
+    lib.rwh_host_inv3.restype = i32
+    lib.rwh_host_inv3.argtypes = [vp, i32, vp, vp]
     lib.rwh_ransac_search.restype = i32
     lib.rwh_ransac_search.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i64, vp, vp, vp, vp, vp, i32, vp]
     lib.rwh_ransac_batched.restype = i32
@@ -83,7 +87,7 @@ def _bind(lib):
     lib.rwh_ransac_run_layout.restype = i32
     lib.rwh_ransac_run_layout.argtypes = [i32, i32, vp, i32]
     lib.rwh_ransac_run.restype = i32
-    lib.rwh_ransac_run.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i32, vp, i32, vp, vp, vp, vp, vp]
+    lib.rwh_ransac_run.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
     return lib
 
 

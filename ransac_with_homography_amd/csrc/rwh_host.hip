@@ -148,3 +148,22 @@ extern "C" int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, 
     for (int b : bads) bad |= b;
     return bad ? RWH_E_LAUNCH : RWH_OK;
 }
+
+// n x (numpy.linalg.inv of a float32 3 x 3, ransac.py:74): float64 dgesv on the identity -- the routine and the library
+// numpy.linalg.inv itself calls -- cast back to float32.  A singular matrix (numpy raises LinAlgError) gives NaNs here.
+extern "C" int rwh_host_inv3(const float* h, int n, void* dgesv_ilp64, float* out) {
+    if (!h || !out || !dgesv_ilp64 || n < 0) return RWH_E_INVALID;
+    typedef void (*dgesv_t)(const int64_t*, const int64_t*, double*, const int64_t*, int64_t*, double*, const int64_t*, int64_t*);
+    dgesv_t f = reinterpret_cast<dgesv_t>(dgesv_ilp64);
+    const int64_t N = 3;
+    for (int t = 0; t < n; ++t) {
+        double a[9], b[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        int64_t ipiv[3], info = 0;
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) a[i + 3 * j] = (double)h[9 * (size_t)t + 3 * i + j];      // column-major, float64 (numpy.linalg)
+        f(&N, &N, a, &N, ipiv, b, &N, &info);
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) out[9 * (size_t)t + 3 * i + j] = info == 0 ? (float)b[i + 3 * j] : __builtin_nanf("");
+    }
+    return RWH_OK;
+}

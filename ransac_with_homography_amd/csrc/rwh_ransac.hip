@@ -343,7 +343,8 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
                                                     float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
                                                     float* __restrict__ errs, const int32_t* __restrict__ offsets,
                                                     int k_per, int mask_stride, const int32_t* __restrict__ stop_needs,
-                                                    unsigned long long* stop_keys, float thf, int filter) {
+                                                    unsigned long long* stop_keys, float thf, int filter,
+                                                    const float* __restrict__ hinvs) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int h_begin, h_end;
@@ -418,7 +419,14 @@ __global__ __launch_bounds__(256) void score_kernel(const float* __restrict__ hs
         float h[9], hi[9];
 #pragma unroll
         for (int i = 0; i < 9; ++i) h[i] = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(hv), 9 * q + i));
-        if constexpr (LOSS != RWH_LOSS_FWD) inverse3(h, hi);
+        if constexpr (LOSS != RWH_LOSS_FWD) {
+            if (hinvs) {                       // the caller's inverses (numpy.linalg.inv's own, for the settle step): uniform loads
+#pragma unroll
+                for (int i = 0; i < 9; ++i) hi[i] = hinvs[9 * (size_t)hyp + i];
+            } else {
+                inverse3(h, hi);
+            }
+        }
         int count = 0;
         auto score = [&](int w, float2 a, float2 b, const Band& bd) {
             const int j = w * 64 + lane;
@@ -500,7 +508,7 @@ __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restri
                                                            float sq_limit, int32_t* __restrict__ counts, uint64_t* __restrict__ masks,
                                                            const int32_t* __restrict__ offsets, int k_per, int mask_stride,
                                                            const int32_t* __restrict__ stop_needs, unsigned long long* stop_keys,
-                                                           float thf) {
+                                                           float thf, const float* __restrict__ hinvs) {
     const int lane = threadIdx.x & 63;
     const int wid = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     int h_begin, h_end;
@@ -564,7 +572,13 @@ __global__ __launch_bounds__(256) void score_filter_kernel(const float* __restri
             const int src = 9 * min(lane, HB - 1);
 #pragma unroll
             for (int i = 0; i < 9; ++i) mine[i] = __shfl(hv, src + i);
-            inverse3(mine, hiv);
+            if (hinvs) {                       // the caller's inverses: lane q takes hypothesis q's
+                const size_t hq = (size_t)min(hyp0 + min(lane, HB - 1), h_end - 1);
+#pragma unroll
+                for (int i = 0; i < 9; ++i) hiv[i] = hinvs[9 * hq + i];
+            } else {
+                inverse3(mine, hiv);
+            }
         }
 #pragma unroll 1
         for (int q = 0; q < nb; ++q, ++cnt_out, mask_out += (MASKS ? mask_stride : 0)) {
@@ -795,7 +809,7 @@ template <int LOSS>
 void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k,
                   int hpw, double th, int32_t* d_counts, uint64_t* d_masks, float* d_err,
                   const int32_t* offsets = nullptr, int k_per = 0, int mask_stride = -1,
-                  const int32_t* stop_needs = nullptr, unsigned long long* stop_keys = nullptr) {
+                  const int32_t* stop_needs = nullptr, unsigned long long* stop_keys = nullptr, const float* d_hinv = nullptr) {
     const dim3 block(256);
     if (mask_stride < 0) mask_stride = words;
     const float sq_limit = score_sq_limit(th);
@@ -804,9 +818,9 @@ void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const f
     const float thf = (float)th;
     if (filter && !d_err && words <= 4) {      // the common case: counts (+ masks) of M <= 256 correspondences
 #define RWH_FILTER(W) do { if (d_masks) hipLaunchKernelGGL((score_filter_kernel<LOSS, W, true>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, \
-                                                          hpw, th, sq_limit, d_counts, d_masks, offsets, k_per, mask_stride, stop_needs, stop_keys, thf); \
+                                                          hpw, th, sq_limit, d_counts, d_masks, offsets, k_per, mask_stride, stop_needs, stop_keys, thf, d_hinv); \
                            else hipLaunchKernelGGL((score_filter_kernel<LOSS, W, false>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, \
-                                                   hpw, th, sq_limit, d_counts, d_masks, offsets, k_per, mask_stride, stop_needs, stop_keys, thf); } while (0)
+                                                   hpw, th, sq_limit, d_counts, d_masks, offsets, k_per, mask_stride, stop_needs, stop_keys, thf, d_hinv); } while (0)
         switch (words) {
             case 1: RWH_FILTER(1); break;
             case 2: RWH_FILTER(2); break;
@@ -824,14 +838,14 @@ void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const f
         const dim3 cgrid((unsigned)(((k + hc - 1) / hc + 3) / 4), (unsigned)chunks);
         if (chunks <= 65535 && hipMemsetAsync(d_counts, 0, sizeof(int32_t) * (size_t)k, s) == hipSuccess) {
             if (d_masks) hipLaunchKernelGGL((score_filter_kernel<LOSS, 4, true, true>), cgrid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hc, th,
-                                            sq_limit, d_counts, d_masks, nullptr, 0, mask_stride, nullptr, nullptr, thf);
+                                            sq_limit, d_counts, d_masks, nullptr, 0, mask_stride, nullptr, nullptr, thf, d_hinv);
             else hipLaunchKernelGGL((score_filter_kernel<LOSS, 4, false, true>), cgrid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hc, th,
-                                    sq_limit, d_counts, d_masks, nullptr, 0, mask_stride, nullptr, nullptr, thf);
+                                    sq_limit, d_counts, d_masks, nullptr, 0, mask_stride, nullptr, nullptr, thf, d_hinv);
             return;
         }
     }
 #define RWH_SCORE(W) hipLaunchKernelGGL((score_kernel<LOSS, W>), grid, block, 0, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, \
-                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride, stop_needs, stop_keys, thf, filter)
+                                        sq_limit, d_counts, d_masks, d_err, offsets, k_per, mask_stride, stop_needs, stop_keys, thf, filter, d_hinv)
     switch (words <= 4 ? words : 0) {
         case 1: RWH_SCORE(1); break;
         case 2: RWH_SCORE(2); break;
@@ -843,9 +857,19 @@ void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const f
 }
 }  // namespace rwh
 
+extern "C" int rwh_score_count_inv(const float* d_h, const float* d_hinv, const float* d_pts_a, const float* d_pts_b, int m, int k,
+                                   double th, int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,
+                                   uint64_t* d_best, float* d_err, void* stream);
+
 extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const float* d_pts_b, int m, int k, double th,
                                int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,
                                uint64_t* d_best, float* d_err, void* stream) {
+    return rwh_score_count_inv(d_h, nullptr, d_pts_a, d_pts_b, m, k, th, loss, need, hyp_base, d_counts, d_masks, d_best, d_err, stream);
+}
+
+extern "C" int rwh_score_count_inv(const float* d_h, const float* d_hinv, const float* d_pts_a, const float* d_pts_b, int m, int k,
+                                   double th, int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,
+                                   uint64_t* d_best, float* d_err, void* stream) {
     using namespace rwh;
     if (!d_h || !d_pts_a || !d_pts_b || !d_counts || !d_best || m <= 0 || k < 0 || hyp_base < 0) return RWH_E_INVALID;
     if (hyp_base + k > 0xFFFFFFFFll) return RWH_E_INVALID;
@@ -862,9 +886,9 @@ extern "C" int rwh_score_count(const float* d_h, const float* d_pts_a, const flo
     if (loss == RWH_LOSS_FWD)
         launch_score<RWH_LOSS_FWD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err);
     else if (loss == RWH_LOSS_BACKWARD)
-        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err);
+        launch_score<RWH_LOSS_BACKWARD>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err, nullptr, 0, -1, nullptr, nullptr, d_hinv);
     else
-        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err);
+        launch_score<RWH_LOSS_REPROJ>(words, grid, s, d_h, d_pts_a, d_pts_b, m, k, hpw, th, d_counts, d_masks, d_err, nullptr, 0, -1, nullptr, nullptr, d_hinv);
     launch_argmax(s, d_counts, k, 1, 0, need, nullptr, (long long)hyp_base, reinterpret_cast<unsigned long long*>(d_best));
     return check_launch();
 }

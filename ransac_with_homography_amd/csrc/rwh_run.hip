@@ -20,7 +20,8 @@
 namespace {
 // sections of the two workspaces (byte offsets, 256-byte aligned)
 enum { D_PA, D_PB, D_IDX, D_H, D_COUNTS, D_FLAGS, D_MASKS, D_BEST, D_HSET, D_CNTSET, D_MASKSET, D_END,
-       H_UP, H_COUNTS, H_FLAGS, H_CNTSET, H_HSET, H_MASK, H_ROWS, H_END, N_OFF };
+       H_UP, H_COUNTS, H_FLAGS, H_CNTSET, H_HSET, H_MASK, H_ROWS, H_END,
+       D_HINVSET, H_HINVSET, N_OFF };      // (round 3, appended: the settled hypotheses' inverses; both lie before D_END / H_END)
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -39,6 +40,7 @@ void layout(int m, int k, long long* off) {
     off[D_HSET] = (long long)d; d = up256(d + 36 * K);
     off[D_CNTSET] = (long long)d; d = up256(d + 4 * K);
     off[D_MASKSET] = (long long)d; d = up256(d + 8 * words * K);
+    off[D_HINVSET] = (long long)d; d = up256(d + 36 * K);
     off[D_END] = (long long)d;
     size_t h = 0;
     off[H_UP] = (long long)h; h = up256(h + (size_t)(off[D_IDX] - off[D_PA]) + 16 * K);
@@ -48,6 +50,7 @@ void layout(int m, int k, long long* off) {
     off[H_HSET] = (long long)h; h = up256(h + 36 * K);
     off[H_MASK] = (long long)h; h = up256(h + 8 * words);
     off[H_ROWS] = (long long)h; h = up256(h + 16 * K);
+    off[H_HINVSET] = (long long)h; h = up256(h + 36 * K);
     off[H_END] = (long long)h;
 }
 
@@ -61,7 +64,7 @@ extern "C" int rwh_ransac_run_layout(int m, int k, long long* offsets, int n_off
 }
 
 extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const int32_t* idx, int k, double th, int loss,
-                              int need, int margin_cap, void* dgesdd_ilp64, int threads, void* d_ws, void* h_ws,
+                              int need, int margin_cap, void* dgesdd_ilp64, void* dgesv_ilp64, int threads, void* d_ws, void* h_ws,
                               int32_t* out, uint64_t* out_mask, void* stream) {
     if (!pts_a || !pts_b || !idx || !d_ws || !h_ws || !out || !out_mask || !dgesdd_ilp64 || m <= 0 || k < 0) return RWH_E_INVALID;
     if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ || margin_cap < 0) return RWH_E_INVALID;
@@ -90,6 +93,11 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
     float* h_hset = reinterpret_cast<float*>(Hh + off[H_HSET]);
     uint64_t* h_mask = reinterpret_cast<uint64_t*>(Hh + off[H_MASK]);
     int32_t* h_rows = reinterpret_cast<int32_t*>(Hh + off[H_ROWS]);
+    float* d_hinvset = reinterpret_cast<float*>(D + off[D_HINVSET]);
+    float* h_hinvset = reinterpret_cast<float*>(Hh + off[H_HINVSET]);
+    // 'backward' / 'reproj' project through numpy.linalg.inv(H): the settled hypotheses get THAT inverse (LAPACK dgesv, rwh_host_inv3),
+    // not the kernel's own elimination, which rounds apart from it on nearly singular H (rwh.h, rwh_score_count_inv)
+    const bool host_inv = loss != RWH_LOSS_FWD && dgesv_ilp64 != nullptr;
 
     for (int i = 0; i < 6; ++i) out[i] = 0;
     out[0] = -1;
@@ -117,8 +125,13 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
         int r = rwh_host_dlt4_svd(pts_a, pts_b, m, samples.data(), n_rows, dgesdd_ilp64, threads, h_hset + 9 * (size_t)nset);
         if (r != RWH_OK) return r;
         if (hipMemcpyAsync(d_hset + 9 * (size_t)nset, h_hset + 9 * (size_t)nset, 36 * (size_t)n_rows, hipMemcpyHostToDevice, s) != hipSuccess) return RWH_E_LAUNCH;
-        r = rwh_score_count(d_hset + 9 * (size_t)nset, d_pa, d_pb, m, n_rows, th, loss, INT_MAX, 0, d_cntset + nset,
-                            d_maskset + (size_t)nset * words, d_best + 4, nullptr, s);
+        if (host_inv) {
+            r = rwh_host_inv3(h_hset + 9 * (size_t)nset, n_rows, dgesv_ilp64, h_hinvset + 9 * (size_t)nset);
+            if (r != RWH_OK) return r;
+            if (hipMemcpyAsync(d_hinvset + 9 * (size_t)nset, h_hinvset + 9 * (size_t)nset, 36 * (size_t)n_rows, hipMemcpyHostToDevice, s) != hipSuccess) return RWH_E_LAUNCH;
+        }
+        r = rwh_score_count_inv(d_hset + 9 * (size_t)nset, host_inv ? d_hinvset + 9 * (size_t)nset : nullptr, d_pa, d_pb, m, n_rows, th, loss,
+                                INT_MAX, 0, d_cntset + nset, d_maskset + (size_t)nset * words, d_best + 4, nullptr, s);
         if (r != RWH_OK) return r;
         if (hipMemcpyAsync(h_cntset + nset, d_cntset + nset, 4 * (size_t)n_rows, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;
         return RWH_OK;

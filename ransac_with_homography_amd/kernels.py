@@ -167,9 +167,10 @@ def scratch_best(device):
     return _scratch_best[key]
 
 
-def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=True, want_err=False):
+def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=True, want_err=False, hinv=None):
     """Launch K2.  Returns (counts [K] int32, masks [K,ceil(M/64)] int64 or None, err [K,M] float32 or None);
-    `best` (from new_best) is updated in place with atomic max."""
+    `best` (from new_best) is updated in place with atomic max.  hinv: [K, 9] float32 on the device, numpy.linalg.inv of every
+    row of H as the reference would compute it ('backward' / 'reproj': rwh_score_count_inv), or None (the kernel's own)."""
     lib = _lib.load()
     _dev_check(H, pts_a, pts_b, best)
     K, M = H.shape[0], pts_a.shape[0]
@@ -177,10 +178,29 @@ def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=Tr
     counts = torch.empty((K,), dtype=torch.int32, device=H.device)
     masks = torch.empty((K, words), dtype=torch.int64, device=H.device) if want_masks else None
     err = torch.empty((K, M), dtype=torch.float32, device=H.device) if want_err else None
-    check(lib.rwh_score_count(_ptr(H), _ptr(pts_a), _ptr(pts_b), M, K, float(th), RWH_LOSS[loss], int(need),
-                              int(hyp_base), _ptr(counts), _ptr(masks) if want_masks else None, _ptr(best),
-                              _ptr(err) if want_err else None, _lib.stream_ptr()), "rwh_score_count")
+    if hinv is not None:
+        assert hinv.dtype == torch.float32 and hinv.is_contiguous() and tuple(hinv.shape) == (K, 9) and hinv.device == H.device
+    check(lib.rwh_score_count_inv(_ptr(H), _ptr(hinv) if hinv is not None else None, _ptr(pts_a), _ptr(pts_b), M, K, float(th),
+                                  RWH_LOSS[loss], int(need), int(hyp_base), _ptr(counts), _ptr(masks) if want_masks else None,
+                                  _ptr(best), _ptr(err) if want_err else None, _lib.stream_ptr()), "rwh_score_count_inv")
     return counts, masks, err
+
+
+def host_inverses(H_rows):
+    """numpy.linalg.inv of every float32 3 x 3 in `H_rows` ([n, 9] host array) exactly as the reference computes it inside its
+    loop (ransac.py:74: float64 LAPACK, cast to float32); a singular matrix gives NaNs instead of numpy's LinAlgError."""
+    H3 = np.ascontiguousarray(H_rows, dtype=np.float32).reshape(-1, 3, 3)
+    with np.errstate(all="ignore"):
+        try:
+            return np.linalg.inv(H3).reshape(-1, 9)
+        except np.linalg.LinAlgError:
+            out = np.full((H3.shape[0], 9), np.nan, dtype=np.float32)
+            for i in range(H3.shape[0]):
+                try:
+                    out[i] = np.linalg.inv(H3[i]).reshape(9)
+                except np.linalg.LinAlgError:
+                    pass
+            return out
 
 
 class SearchWorkspace:
@@ -225,9 +245,9 @@ class RunWorkspace:
     def __init__(self, m, k, device):
         lib = _lib.load()
         self.m, self.k, self.words = int(m), int(k), (int(m) + 63) // 64
-        off = (ctypes.c_longlong * 20)()
-        n = lib.rwh_ransac_run_layout(self.m, self.k, off, 20)
-        if n != 20:
+        off = (ctypes.c_longlong * 22)()
+        n = lib.rwh_ransac_run_layout(self.m, self.k, off, 22)
+        if n != 22:
             check(n if n < 0 else _lib_invalid(), "rwh_ransac_run_layout")
         self.off = list(off)
         self.dev = torch.empty(self.off[self.D_END], dtype=torch.uint8, device=device)
@@ -272,7 +292,7 @@ def _lib_invalid():
     return -1
 
 
-def ransac_run(pts_a, pts_b, idx, th, loss, need, margin_cap, ws, dgesdd, threads):
+def ransac_run(pts_a, pts_b, idx, th, loss, need, margin_cap, ws, dgesdd, threads, dgesv=None):
     """rwh_ransac_run: upload + search + settle + accept rules in ONE native call.  pts_a / pts_b: float32 [M, 2] HOST arrays,
     idx: int32 [K, 4] host array.  -> (winner | None, early, count, host_solved, rounds, flagged, mask_words uint64 [words])."""
     lib = _lib.load()
@@ -282,7 +302,8 @@ def ransac_run(pts_a, pts_b, idx, th, loss, need, margin_cap, ws, dgesdd, thread
     out = np.zeros(6, dtype=np.int32)
     mask = np.zeros(ws.words, dtype=np.uint64)
     check(lib.rwh_ransac_run(pts_a.ctypes.data, pts_b.ctypes.data, ws.m, idx.ctypes.data, ws.k, float(th), RWH_LOSS[loss], int(need),
-                             int(margin_cap), ctypes.c_void_p(dgesdd), int(threads), _ptr(ws.dev), ctypes.c_void_p(ws.host.data_ptr()),
+                             int(margin_cap), ctypes.c_void_p(dgesdd), ctypes.c_void_p(dgesv or 0), int(threads), _ptr(ws.dev),
+                             ctypes.c_void_p(ws.host.data_ptr()),
                              out.ctypes.data, mask.ctypes.data, _lib.stream_ptr()), "rwh_ransac_run")
     winner = int(out[0])
     return (winner if winner >= 0 else None), bool(out[1]), int(out[2]), int(out[3]), int(out[4]), int(out[5]), mask

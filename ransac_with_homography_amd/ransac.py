@@ -156,6 +156,18 @@ class _Settled(object):
         return {i: self.batches[b][1][j] for i, (b, j) in self.where.items()}
 
 
+def _score_settled(H, pa_dev, pb_dev, th, method):
+    """K2 on hypotheses the host solved (H: [n, 9] float32 host array) -> (counts, masks) device tensors.  'backward' and
+    'reproj' project through numpy.linalg.inv(H) (ransac.py:74): these rows get numpy's own inverse, not the kernel's
+    elimination, which rounds apart from LAPACK's on nearly singular H (rwh.h, rwh_score_count_inv)."""
+    import torch
+    dev = pa_dev.device
+    hd = torch.from_numpy(H).to(dev)
+    hinv = None if method == "fwd" else torch.from_numpy(kernels.host_inverses(H)).to(dev)
+    cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.scratch_best(dev), hinv=hinv)
+    return cnt, msk
+
+
 def presettle(pa_dev, pb_dev, pa, pb, idx_host, rows, th, method):
     """First part of the settle step, for samples the HOST can name before the GPU has said anything (repeated indices):
     their reference H by `svd_hypotheses` -- host time that overlaps the search already enqueued on the GPU -- then K2 on
@@ -165,8 +177,7 @@ def presettle(pa_dev, pb_dev, pa, pb, idx_host, rows, th, method):
     if rows.size == 0:
         return None
     H = svd_hypotheses(pa, pb, idx_host[rows][:, :4])
-    hd = torch.from_numpy(H).to(pa_dev.device)
-    cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.scratch_best(pa_dev.device))
+    cnt, msk = _score_settled(H, pa_dev, pb_dev, th, method)
     return rows, H, cnt, msk
 
 
@@ -208,8 +219,7 @@ def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, m
             break
         n_rounds += 1
         H = svd_hypotheses(pa, pb, idx_host[cand][:, :4])
-        hd = torch.from_numpy(H).to(pa_dev.device)
-        cnt, msk, _ = kernels.score_count(hd, pa_dev, pb_dev, th, method, 1 << 30, kernels.scratch_best(pa_dev.device))
+        cnt, msk = _score_settled(H, pa_dev, pb_dev, th, method)
         counts[cand] = cnt.cpu().numpy()
         st.add(cand, H, msk)
     if stats is not None:
@@ -287,10 +297,10 @@ class HomoModel(Model):
         if val.dtype == np.float32 and x.dtype == np.float32 and nrow == 2:
             # the RANSAC loop's own case: float32 H, w == 1, inverse by the kernel's float64 LU (bit-identical to numpy's)
             if inverse:
-                np.linalg.inv(val)                        # (for its LinAlgError on a singular val, ransac.py:74)
-            h9 = torch.from_numpy(np.ascontiguousarray(val).reshape(9)).to(dev)
+                val = np.linalg.inv(val)                  # ransac.py:74: numpy's own float32 inverse (LinAlgError on a singular val);
+            h9 = torch.from_numpy(np.ascontiguousarray(val).reshape(9)).to(dev)      # the kernel then projects forward through it
             pts = torch.from_numpy(np.ascontiguousarray(x[:2].T)).to(dev)
-            return kernels.project_points(h9, pts, inverse).cpu().numpy()
+            return kernels.project_points(h9, pts, False).cpu().numpy()
         if inverse:
             val = np.linalg.inv(val)                      # ransac.py:74: float64 inside, result in val's dtype
         dt = np.result_type(val.dtype, x.dtype)
@@ -337,7 +347,8 @@ class HomoModel(Model):
         pa = torch.from_numpy(_points_rows(X)).to(dev)
         pb = torch.from_numpy(_points_rows(Y)).to(dev)
         best = kernels.new_best(dev)
-        _, _, err = kernels.score_count(h9, pa, pb, 0.0, method, 1 << 30, best, want_masks=False, want_err=True)
+        hinv = None if method == "fwd" else torch.from_numpy(kernels.host_inverses(np.asarray(self.val, dtype=np.float32).reshape(1, 9))).to(dev)
+        _, _, err = kernels.score_count(h9, pa, pb, 0.0, method, 1 << 30, best, want_masks=False, want_err=True, hinv=hinv)
         return err[0].cpu().numpy()
 
 
@@ -412,7 +423,8 @@ class RANSAC(object):
             # (repeated-index samples solved on host threads while the GPU searches), the accept rules
             ws = kernels.RunWorkspace(mx, k, dev)
             winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words = kernels.ransac_run(
-                pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS)
+                pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS,
+                dgesv=None if method == "fwd" else _lapack.dgesv_address())
             counts_host = ws.host_counts(settled=True)
             stats = {"raw_counts": ws.host_counts(), "host_settled": n_set, "host_rounds": n_rounds, "flagged": n_flagged}
             Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks

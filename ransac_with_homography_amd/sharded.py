@@ -81,8 +81,9 @@ def winner_inliers(pa, pb, idx_row, th, loss):
     from . import kernels
     from .ransac import svd_hypotheses
     H = svd_hypotheses(pa.cpu().numpy(), pb.cpu().numpy(), np.asarray(idx_row).reshape(1, 4))
+    hinv = None if loss == "fwd" else torch.from_numpy(kernels.host_inverses(H)).to(pa.device)      # numpy's own inverse (ransac.py:74)
     counts, masks, _ = kernels.score_count(torch.from_numpy(H).to(pa.device), pa, pb, th, loss, 1 << 30,
-                                           kernels.new_best(pa.device))
+                                           kernels.new_best(pa.device), hinv=hinv)
     bits = np.unpackbits(masks[0].cpu().numpy().view(np.uint8), bitorder="little")[:pa.shape[0]]
     return np.nonzero(bits)[0].astype(np.int64), int(counts[0])
 

@@ -57,16 +57,18 @@ def test_round3_host_entry_points_without_gpu(lib):
     """rwh_ransac_run_layout (pure arithmetic), argument validation of rwh_ransac_run / rwh_host_dlt4_svd / rwh_lab_clock_probe,
     and the host solver itself -- rwh_host_dlt4_svd needs no GPU: it must reproduce the reference's H on golden samples."""
     from ransac_with_homography_amd import _lapack
-    off = (ctypes.c_longlong * 20)()
-    assert lib.rwh_ransac_run_layout(185, 1500, off, 20) == 20
+    off = (ctypes.c_longlong * 22)()
+    assert lib.rwh_ransac_run_layout(185, 1500, off, 22) == 22
     o = list(off)
-    assert o[0] == 0 and all(b >= a for a, b in zip(o[:12], o[1:12])) and all(b >= a for a, b in zip(o[12:19], o[13:20]))
+    assert o[0] == 0 and all(b >= a for a, b in zip(o[:11], o[1:11])) and all(b >= a for a, b in zip(o[12:18], o[13:19]))
     assert o[5] == o[4] + 4 * 1500 and o[14] == o[13] + 4 * 1500            # counts and flags adjacent: one readback
-    assert o[11] > 36 * 1500 * 2 and o[19] > 16 * 1500
-    assert lib.rwh_ransac_run_layout(185, 1500, off, 19) == -1 and lib.rwh_ransac_run_layout(0, 10, off, 20) == -1
+    assert o[11] > 36 * 1500 * 3 and o[19] > 16 * 1500 + 36 * 1500
+    assert o[10] < o[20] < o[11] and o[18] < o[21] < o[19]                  # the inverses of the settled rows: inside both workspaces
+    assert lib.rwh_ransac_run_layout(185, 1500, off, 21) == -1 and lib.rwh_ransac_run_layout(0, 10, off, 22) == -1
     null = ctypes.c_void_p(0)
-    assert lib.rwh_ransac_run(null, null, 185, null, 10, 5.0, 0, 100, 8, null, 1, null, null, null, null, null) == -1
+    assert lib.rwh_ransac_run(null, null, 185, null, 10, 5.0, 0, 100, 8, null, null, 1, null, null, null, null, null) == -1
     assert lib.rwh_host_dlt4_svd(null, null, 185, null, 4, null, 1, null) == -1
+    assert lib.rwh_host_inv3(null, 4, null, null) == -1 and lib.rwh_score_count_inv(null, null, null, null, 4, 4, 1.0, 0, 1, 0, null, null, null, null, null) == -1
     assert lib.rwh_lab_clock_probe(null, 1.0, null) == -1
     addr = _lapack.dgesdd_address()
     if addr is None:
@@ -80,6 +82,23 @@ def test_round3_host_entry_points_without_gpu(lib):
     assert np.array_equal(out.view(np.uint32), g["H"][:500].view(np.uint32))
     bad = idx.copy(); bad[7, 2] = 185                                              # an index past the table: refused, nothing read
     assert lib.rwh_host_dlt4_svd(pa.ctypes.data, pb.ctypes.data, 185, bad.ctypes.data, 500, ctypes.c_void_p(addr), 3, out.ctypes.data) == -1
+    # rwh_host_inv3 == numpy.linalg.inv on float32 3 x 3 matrices, bit for bit -- well-conditioned, pixel-scaled and nearly singular
+    # ones (rank 2 plus 1e-9 .. 1e-3 of noise: where the kernels' own elimination and LAPACK's round apart)
+    gesv = _lapack.dgesv_address()
+    assert gesv is not None
+    rng = np.random.default_rng(0)
+    n = 5000
+    well = (np.eye(3) + rng.normal(0, 0.3, (n, 3, 3))).astype(np.float32)
+    u, v, w, x = (rng.normal(0, 1, sh) for sh in ((n, 3, 1), (n, 1, 3), (n, 3, 1), (n, 1, 3)))
+    ill = (u @ v + w @ x + 10.0 ** rng.uniform(-9, -3, (n, 1, 1)) * rng.normal(0, 1, (n, 3, 3))).astype(np.float32)
+    pix = well.copy(); pix[:, :2, 2] *= 300; pix[:, 2, :2] *= 1e-5
+    for mats in (well, ill, pix, g["H"][:2000].reshape(-1, 3, 3).copy()):
+        mats = np.ascontiguousarray(mats[np.isfinite(mats).all(axis=(1, 2))])
+        got = np.empty_like(mats)
+        assert lib.rwh_host_inv3(mats.ctypes.data, len(mats), ctypes.c_void_p(gesv), got.ctypes.data) == 0
+        with np.errstate(all="ignore"):
+            want = np.linalg.inv(mats)
+        assert want.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
 
 
 def test_new_entry_points_validate_and_plan(lib):

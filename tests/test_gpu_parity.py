@@ -1882,6 +1882,51 @@ def test_host_helpers_and_interpolators_vs_reference(gpu, auto_mode):
     assert not wrong, wrong
 
 
+def test_ransac_run_near_singular_inverse_vs_reference(gpu):
+    """g19 (written by the unmodified reference): cluster problems under 'backward' / 'reproj'.  A sample drawn from two or three
+    tight clusters gives a nearly singular H; the reference inverts every hypothesis with numpy.linalg.inv (ransac.py:74) and the
+    loss then depends on how THAT routine rounds -- the kernels' own float64 elimination rounds apart from it there (case 0:
+    same winner and count, another inlier list; found by tools/soak_settle.py).  The settle step scores its hypotheses with
+    numpy's own inverses (rwh_host_inv3 / rwh_score_count_inv): winner, count, inlier list, refit and generator position of
+    every run, through the native driver and through its Python twin."""
+    import contextlib
+    import io
+    import ransac as rs
+    from ransac_with_homography_amd import ransac as rmod
+    from test_oracle_golden import _g19_cases
+    g = load_golden("g19_near_singular_inverse")
+    for force in (False, True):
+        rmod.FORCE_PYTHON_DRIVER = force
+        try:
+            for key, A, B, th, d, k, n, seed, m in _g19_cases(g):
+                np.random.seed(seed)
+                with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+                    r = rs.RANSAC(rs.HomoModel(th=th, d=d, n=n), k=k)
+                    H, inl, cnt = r.run([A.T, B.T], method=m)
+                assert int(cnt) == int(g[key + "_count"]) and np.array_equal(inl[0], g[key + "_inliers"]), (key, force, int(cnt), int(g[key + "_count"]))
+                assert int(np.random.randint(0, 1 << 30)) == int(g[key + "_next_draw"]), (key, force)
+                assert np.allclose(H, g[key + "_H"], rtol=1e-3, atol=1e-6), (key, force)
+        finally:
+            rmod.FORCE_PYTHON_DRIVER = False
+    # the single-call helpers take numpy's inverse too: a nearly singular val, bit for bit against the reference's expressions
+    key, A, B, th, d, k, n, seed, m = next(_g19_cases(g))
+    rng = np.random.default_rng(5)
+    for t in range(40):
+        idx = rng.integers(0, len(A), 4)
+        with np.errstate(all="ignore"):
+            val = np.asarray(rs.HomoModel().fit(A[idx].T, B[idx].T))
+            if not np.isfinite(val).all():
+                continue
+            mod = rs.HomoModel(); mod.val = val
+            x = np.ones((3, len(A)), np.float32); x[:2] = B.T
+            want = np.linalg.inv(val) @ x
+            want = want / (want[-1, :] + 1e-10)
+            assert np.array_equal(mod.reproj(B.T), want, equal_nan=True), t
+            e = mod.computeLoss(A.T, B.T, "backward")
+            dlt = want[:2] - A.T
+            assert np.array_equal(e, np.sqrt(np.sum(dlt * dlt, axis=0)), equal_nan=True), t
+
+
 def test_ransac_run_edge_cases_vs_reference(gpu):
     """g14 (written by the unmodified reference): the corners of RANSAC.run's input space -- one to four correspondences, none,
     k = 0 / 1, thresholds of 0, below 0 and huge, d of 0 and beyond the number of points, n < 4 and n > M, all points equal,

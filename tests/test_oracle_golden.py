@@ -383,3 +383,24 @@ def test_oracle_host_helpers_and_interpolators_g18(matches):
         elif want == "ok":
             _g18_check(name, r, args, outs, after, wrong)
     assert not wrong, wrong
+
+
+def _g19_cases(g):
+    for i in range(int(g["n_cases"])):
+        key = "c%d" % i
+        th, d, k, n, seed = g[key + "_par"]
+        yield key, g[key + "_A"], g[key + "_B"], float(th), int(d), int(k), int(n), int(seed), str(g[key + "_method"])
+
+
+def test_oracle_ransac_near_singular_inverse_g19():
+    """g19: cluster problems under 'backward' / 'reproj' -- hypotheses whose matrix is nearly singular, where the loss depends on
+    HOW numpy.linalg.inv rounds (ransac.py:74).  The oracle calls the same numpy routine: count, inlier list, generator."""
+    import contextlib
+    import io
+    g = load_golden("g19_near_singular_inverse")
+    for key, A, B, th, d, k, n, seed, m in _g19_cases(g):
+        np.random.seed(seed)
+        with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+            H, inl, cnt, _ = orc.ransac_run(A.T, B.T, th=th, d=d, n=n, k=k, method=m)
+        assert int(cnt) == int(g[key + "_count"]) and np.array_equal(inl[0], g[key + "_inliers"]), key
+        assert int(np.random.randint(0, 1 << 30)) == int(g[key + "_next_draw"]), key
