@@ -179,7 +179,10 @@ RWH_API int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, int
                                 (three collinear source points, equal coordinates at different indices, ...) or a unit null
                                 vector whose 9th element is below 1e-7: H is finite but K1's elimination and LAPACK's SVD
                                 (the reference's solver) may round to different float32 H.  RANSAC.run re-derives flagged
-                                samples on the host with the reference's own solver; ~2 % of the samples on natural matches. */
+                                samples on the host with the reference's own solver; ~2 % of the samples on natural matches.
+                                In searches that invert the hypotheses (rwh_ransac_search / _batched with 'backward' or 'reproj')
+                                the bit is also set for a nearly singular H (|det| below 1e-6 of the sum of the six products'
+                                magnitudes): its inverse must be numpy.linalg.inv's own (rwh_score_count_inv). */
 RWH_API int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m,
                      const int32_t* d_idx, int k,
                      float* d_h, uint8_t* d_flags, void* stream);

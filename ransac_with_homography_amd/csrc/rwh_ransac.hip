@@ -46,7 +46,7 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
                                                   const int32_t* __restrict__ idx, int k,
                                                   float* __restrict__ hout, uint8_t* __restrict__ flags,
                                                   const int32_t* __restrict__ offsets, int k_per,
-                                                  unsigned long long* __restrict__ reset_keys, int n_reset) {
+                                                  unsigned long long* __restrict__ reset_keys, int n_reset, int flag_near_singular) {
     __shared__ float hstage[64 * 9];
     const int t = blockIdx.x * 64 + threadIdx.x;
     // a search's packed argmax keys are cleared here instead of by a memset launch of their own (the grid always
@@ -160,11 +160,26 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
 #pragma unroll
     for (int i = 0; i < 9; ++i) n[i] = (float)(h[i] * rnrm);
     bool finite = true;
+    double q[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) {
         const float v = n[i] / n[8];
         finite &= (fabsf(v) <= 3.4028234664e38f);  // false for NaN / inf
         hstage[9 * threadIdx.x + i] = v;
+        q[i] = (double)v;
+    }
+    // ... and, for searches that will INVERT the hypotheses ('backward' / 'reproj': numpy.linalg.inv of every one, ransac.py:74),
+    // a nearly singular H -- a sample drawn from two or three tight clusters, or simply a bad one: where the determinant is what
+    // is left of six products that cancel below 1e-6 of their size, LAPACK's float64 elimination and any other round apart
+    // after the cast to float32 (measured against numpy on 17 555 cluster-problem hypotheses: 286 of the 287 differing inverses
+    // have a ratio below 1e-7, the last one 4e-7; none above 1e-5 in 27 000).  The settle step gives the flagged ones numpy's
+    // own inverse (rwh_score_count_inv).  5-12 % of the samples of a real, contaminated match set trip it.
+    if (flag_near_singular) {
+        const double t0 = q[0] * q[4] * q[8], t1 = q[1] * q[5] * q[6], t2 = q[2] * q[3] * q[7];
+        const double t3 = q[2] * q[4] * q[6], t4 = q[1] * q[3] * q[8], t5 = q[0] * q[5] * q[7];
+        const double det = (t0 + t1 + t2) - (t3 + t4 + t5);
+        const double perm = fabs(t0) + fabs(t1) + fabs(t2) + fabs(t3) + fabs(t4) + fabs(t5);
+        illcond |= !(fabs(det) > 1e-6 * perm);
     }
     if (live) flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR) |
                                    (illcond ? RWH_HYP_ILLCOND : 0u));
@@ -763,10 +778,10 @@ extern "C" int rwh_project_points(const float* d_h, const float* d_pts, int m, i
 namespace rwh {
 static void launch_dlt4(hipStream_t s, const float* d_pts_a, const float* d_pts_b, int m, const int32_t* d_idx, int k,
                         float* d_h, uint8_t* d_flags, const int32_t* offsets, int k_per, unsigned long long* reset_keys,
-                        int n_reset) {
+                        int n_reset, int flag_near_singular = 0) {
     const int threads = k > n_reset ? k : n_reset;
     hipLaunchKernelGGL(dlt4_kernel, dim3((threads + 63) / 64), dim3(64), 0, s, d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags,
-                       offsets, k_per, reset_keys, n_reset);
+                       offsets, k_per, reset_keys, n_reset, flag_near_singular);
 }
 
 static void launch_argmax(hipStream_t s, const int32_t* d_counts, int k, int n_problems, int k_per, int need,
@@ -901,7 +916,7 @@ extern "C" int rwh_ransac_search(const float* d_pts_a, const float* d_pts_b, int
     // the DLT launch also clears the two keys (saves a memset launch per search)
     if (k > 0 || reset_best)
         launch_dlt4(static_cast<hipStream_t>(stream), d_pts_a, d_pts_b, m, d_idx, k, d_h, d_flags, nullptr, 0,
-                    reset_best ? reinterpret_cast<unsigned long long*>(d_best) : nullptr, reset_best ? 2 : 0);
+                    reset_best ? reinterpret_cast<unsigned long long*>(d_best) : nullptr, reset_best ? 2 : 0, loss != RWH_LOSS_FWD);
     const int st = check_launch();
     if (st != RWH_OK) return st;
     return rwh_score_count(d_h, d_pts_a, d_pts_b, m, k, th, loss, need, hyp_base, d_counts, d_masks, d_best, nullptr, stream);
@@ -924,7 +939,7 @@ extern "C" int rwh_ransac_batched(const float* d_pts_a, const float* d_pts_b, co
         hipLaunchKernelGGL(sample4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d_offsets, n_problems, k,
                            (unsigned long long)seed, (unsigned)problem_base, d_idx);
     launch_dlt4(s, d_pts_a, d_pts_b, m_max, d_idx, (int)total, d_h, d_flags, d_offsets, k,
-                reinterpret_cast<unsigned long long*>(d_best), 2 * n_problems);   // also clears the P x 2 keys
+                reinterpret_cast<unsigned long long*>(d_best), 2 * n_problems, loss != RWH_LOSS_FWD);   // also clears the P x 2 keys
     int hpw = (int)(total / 14000);
     hpw = hpw < 1 ? 1 : (hpw > 14 ? 14 : hpw);
     if (g_force_score_hpw) hpw = g_force_score_hpw;   // lab override (rwh_lab_tune)

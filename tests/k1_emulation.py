@@ -8,7 +8,7 @@ import numpy as np
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND = 1, 2, 4
 
 
-def dlt4(pa, pb, idx):
+def dlt4(pa, pb, idx, near_singular=False):
     """pa, pb: float32 [M, 2]; idx: int [K, 4] -> (H float32 [K, 9], flags uint8 [K])."""
     idx = np.asarray(idx)[:, :4]
     K = idx.shape[0]
@@ -56,6 +56,13 @@ def dlt4(pa, pb, idx):
         H = n / n[:, 8:9]
         illcond = ~(ss <= 1e14) | ~(ratios >= 1e-3).all(axis=1)
         finite = np.isfinite(H).all(axis=1)
+        # a nearly singular H: |det| against the sum of the six products' magnitudes (rwh_ransac.hip, dlt4_kernel)
+        q = H.astype(np.float64)
+        t = [q[:, 0] * q[:, 4] * q[:, 8], q[:, 1] * q[:, 5] * q[:, 6], q[:, 2] * q[:, 3] * q[:, 7],
+             q[:, 2] * q[:, 4] * q[:, 6], q[:, 1] * q[:, 3] * q[:, 8], q[:, 0] * q[:, 5] * q[:, 7]]
+        det = (t[0] + t[1] + t[2]) - (t[3] + t[4] + t[5])
+        if near_singular:
+            illcond |= ~(np.abs(det) > 1e-6 * sum(np.abs(v) for v in t))
     a, b, c, d = (idx[:, i] for i in range(4))
     rep = (a == b) | (a == c) | (a == d) | (b == c) | (b == d) | (c == d)
     flags = (rep * RWH_HYP_REPEATED + (~finite) * RWH_HYP_SINGULAR + illcond * RWH_HYP_ILLCOND).astype(np.uint8)
