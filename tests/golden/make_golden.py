@@ -757,7 +757,7 @@ def g18(ptsA, ptsB):
 def g19(ptsA, ptsB):
     """Nearly singular hypotheses under 'backward' / 'reproj' (ransac.py:74 inverts every hypothesis with numpy.linalg.inv): cluster
     problems -- samples drawn from two or three tight clusters give H that numpy's float64 LAPACK inverse and any other float64
-    elimination round apart, and with them the losses.  Case 0 is case 266 of `tools/soak_settle.py 2000 109` (the run that found
+    elimination round apart, and with them the losses.  Case 0 is case 266 of `tests/soak_settle.py 2000 109` (the run that found
     it: same winner and count, a different inlier list); the others are more of its kind.  The reference's own runs."""
     rng = np.random.default_rng(109)
     HS = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
@@ -766,7 +766,7 @@ def g19(ptsA, ptsB):
         P = np.concatenate([G, np.ones((len(G), 1))], 1) @ HS.T
         return P[:, :2] / P[:, 2:3] + rng.normal(0, noise, (len(G), 2))
 
-    def problem(kind):          # tools/soak_settle.py's generator, draw for draw
+    def problem(kind):          # tests/soak_settle.py's generator, draw for draw
         if kind == 0:
             M = int(rng.integers(30, 900)); nx, ny = int(rng.integers(2, 20)), int(rng.integers(2, 12))
             G = np.stack([rng.integers(0, nx, M) * rng.uniform(5, 100), rng.integers(0, ny, M) * rng.uniform(5, 100)], 1)

@@ -1,9 +1,9 @@
-"""Developer soak test (not part of the suite): RANSAC.run against the CPU oracle (the reference's loop, same numpy seed) on random
+"""Soak test (lives under tests/ because it calls the oracle; not collected by pytest): RANSAC.run against the CPU oracle (the reference's loop, same numpy seed) on random
 problems from families that stress the settle step -- lattices (collinear triples, equal coordinates at different indices),
 tight clusters, heavy contamination (the winner is often a repeated-index sample), tiny problems (M = 5..12: most samples repeat
 an index), large coordinates -- with random th / d / k / n / loss.  Every run must return the oracle's winner iteration,
 count and inlier list and leave numpy's generator where the oracle leaves it.
-   python tools/soak_settle.py [cases] [seed]"""
+   python tests/soak_settle.py [cases] [seed]"""
 import contextlib, io, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

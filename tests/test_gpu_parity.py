@@ -1724,7 +1724,7 @@ def test_host_transfer_pipeline_round_trip(gpu):
 
 
 def test_ransac_run_random_problem_families_vs_oracle(gpu):
-    """A short version of tools/soak_settle.py inside the suite: RANSAC.run against the oracle's sequential loop (same numpy
+    """A short version of tests/soak_settle.py inside the suite: RANSAC.run against the oracle's sequential loop (same numpy
     seed) on random lattice / cluster / contaminated / tiny / large-coordinate problems with random th, d, k, n and loss:
     winner iteration, count, inlier list, the generator's position -- or the same failure (a winner with fewer inliers than
     the refit accepts, ransac.py:38)."""
@@ -1886,7 +1886,7 @@ def test_ransac_run_near_singular_inverse_vs_reference(gpu):
     """g19 (written by the unmodified reference): cluster problems under 'backward' / 'reproj'.  A sample drawn from two or three
     tight clusters gives a nearly singular H; the reference inverts every hypothesis with numpy.linalg.inv (ransac.py:74) and the
     loss then depends on how THAT routine rounds -- the kernels' own float64 elimination rounds apart from it there (case 0:
-    same winner and count, another inlier list; found by tools/soak_settle.py).  The settle step scores its hypotheses with
+    same winner and count, another inlier list; found by tests/soak_settle.py).  The settle step scores its hypotheses with
     numpy's own inverses (rwh_host_inv3 / rwh_score_count_inv): winner, count, inlier list, refit and generator position of
     every run, through the native driver and through its Python twin."""
     import contextlib
