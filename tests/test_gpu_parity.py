@@ -1908,6 +1908,13 @@ def test_ransac_run_near_singular_inverse_vs_reference(gpu):
                 assert np.allclose(H, g[key + "_H"], rtol=1e-3, atol=1e-6), (key, force)
         finally:
             rmod.FORCE_PYTHON_DRIVER = False
+    # the batched form with the caller's index tables settles the same way
+    for key, A, B, th, d, k, n, seed, m in list(_g19_cases(g))[:6]:
+        np.random.seed(seed)
+        table = np.random.randint(0, len(A), (k, n))
+        with np.errstate(all="ignore"), contextlib.redirect_stdout(io.StringIO()):
+            (Hb, inlb, cntb), = rmod.run_batch([[A.T, B.T]], th=th, d=d, n=n, k=k, method=m, idx=[table])
+        assert int(cntb) == int(g[key + "_count"]) and np.array_equal(inlb[0], g[key + "_inliers"]), (key, "run_batch")
     # the single-call helpers take numpy's inverse too: a nearly singular val, bit for bit against the reference's expressions
     key, A, B, th, d, k, n, seed, m = next(_g19_cases(g))
     rng = np.random.default_rng(5)
