@@ -418,13 +418,14 @@ class RANSAC(object):
         need_i = kernels.need_count(mx, self.d, self.n)
         th = _weak_threshold(self.th)
         addr = _lapack.dgesdd_address()
-        if addr is not None and not FORCE_PYTHON_DRIVER:
+        gesv = None if method == "fwd" else _lapack.dgesv_address()
+        if addr is not None and not FORCE_PYTHON_DRIVER and (method == "fwd" or gesv is not None):
             # the whole driver in ONE native call (rwh_ransac_run, csrc/rwh_run.hip): upload, K1 + K2 + argmax, the settle step
             # (repeated-index samples solved on host threads while the GPU searches), the accept rules
             ws = kernels.RunWorkspace(mx, k, dev)
             winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words = kernels.ransac_run(
                 pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS,
-                dgesv=None if method == "fwd" else _lapack.dgesv_address())
+                dgesv=gesv)
             counts_host = ws.host_counts(settled=True)
             stats = {"raw_counts": ws.host_counts(), "host_settled": n_set, "host_rounds": n_rounds, "flagged": n_flagged}
             Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
