@@ -86,9 +86,23 @@ def _weak_threshold(th):
     return float(th)
 
 
+_warned_dtype = False
+
+
 def _points_rows(P):
-    """features x observations (2 x M or 3 x M) -> contiguous M x 2 float32."""
+    """features x observations (2 x M or 3 x M) -> contiguous M x 2 float32.
+
+    The search kernels take float32 correspondences -- what the reference's own pipeline hands to RANSAC.run (ransac.py:263-267:
+    np.float32 keypoints).  Other dtypes are cast, with a warning (once): on float64 or integer arrays the reference forms the DLT
+    products and the distances in THAT dtype (homography.py:6-13, ransac.py:78-82), so its last bits -- and with them a borderline
+    inlier -- can differ from what the float32 path returns."""
+    global _warned_dtype
     P = np.asarray(P)
+    if P.dtype != np.float32 and not _warned_dtype:
+        import warnings
+        _warned_dtype = True
+        warnings.warn("RANSAC: %s correspondences are cast to float32 (the reference's pipeline passes float32; on other dtypes it "
+                      "computes products and distances in that dtype, which this path does not reproduce bit for bit)" % P.dtype, stacklevel=3)
     return np.ascontiguousarray(P.T[:, :2], dtype=np.float32)
 
 
