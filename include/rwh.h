@@ -357,6 +357,17 @@ RWH_API int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const voi
                         int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
                         int blend, double rate, void* d_canvas, unsigned flags, void* stream);
 
+/*
+ * The same, canvas rows [row_begin, row_end) only (d_canvas still points at row 0; always the exact kernel): lets a host layer
+ * that gets its images as host arrays compose a row tile as soon as the image rows it reads have arrived, and send it
+ * back while later rows are still on their way up (full-duplex PCIe).  RWH_WARP_ZERO_ORIGIN: pass it with the FIRST tile
+ * only (it writes texel (0,0) of imgT).
+ */
+RWH_API int rwh_stitch_panorama_rows(const void* d_img_t, int t_h, int t_w, const void* d_img_q, int q_h, int q_w,
+                             const double* inv_h, int grid_x0, int grid_y0, int warp_w, int warp_h,
+                             int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
+                             int blend, double rate, void* d_canvas, int row_begin, int row_end, unsigned flags, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

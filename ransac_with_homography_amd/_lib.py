@@ -25,7 +25,7 @@ RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT = 0, 1, 2
 # every symbol include/rwh.h declares (tests check the library exports them all)
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama",
-           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check", "rwh_score_count_inv", "rwh_host_inv3")
+           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check", "rwh_score_count_inv", "rwh_host_inv3", "rwh_stitch_panorama_rows")
 
 
 class RwhUnavailable(RuntimeError):
@@ -78,6 +78,9 @@ def _bind(lib):
     lib.rwh_stitch_panorama.restype = i32
     lib.rwh_stitch_panorama.argtypes = [vp, i32, i32, vp, i32, i32, c.POINTER(f64), i32, i32, i32, i32,
                                         i32, i32, i32, i32, i32, i32, i32, f64, vp, u32, vp]
+    lib.rwh_stitch_panorama_rows.restype = i32
+    lib.rwh_stitch_panorama_rows.argtypes = [vp, i32, i32, vp, i32, i32, c.POINTER(f64), i32, i32, i32, i32,
+                                             i32, i32, i32, i32, i32, i32, i32, f64, vp, i32, i32, u32, vp]
     lib.rwh_project_points_ex.restype = i32
     lib.rwh_project_points_ex.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.rwh_project_points.restype = i32

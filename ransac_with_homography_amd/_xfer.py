@@ -33,12 +33,66 @@ class _Pipe(object):
         self.lock = threading.Lock()
 
 
+_side = {}
+
+
+def side_stream(dev, name):
+    """A long-lived side stream per (device, name): the pipelined stitch composes on one and downloads on another."""
+    import torch
+    key = (dev.type, dev.index, name)
+    with _lock:
+        if key not in _side:
+            _side[key] = torch.cuda.Stream(dev)
+        return _side[key]
+
+
 def _pipe(dev):
     key = (dev.type, dev.index)
     with _lock:
         if key not in _pipes:
             _pipes[key] = _Pipe(dev)
         return _pipes[key]
+
+
+def upload_tasks(tasks, dev, on_chunk=None, join=True):
+    """Staged host -> device copies in the caller's order.  tasks: iterable of (src, dst, off, m, tag) -- `m` bytes at byte offset `off`
+    of the flat uint8 numpy array `src` to the same offset of the flat uint8 device tensor `dst` (m <= CHUNK).  Host threads fill the
+    page-locked ring, the DMA engine drains it on the pipe's own stream.  on_chunk(tag, off + m, event) runs on the calling thread
+    right after a chunk's DMA has been enqueued (`event` fires when it has landed).  join: make torch's current stream wait for
+    the whole upload."""
+    import torch
+    p = _pipe(dev)
+    with p.lock:
+        cur = torch.cuda.current_stream(dev)
+        p.stream.wait_stream(cur)                                  # the destinations belong to the current stream's allocator history
+        events = [None] * SLOTS
+        staged = deque()
+        with torch.cuda.stream(p.stream):
+            def issue():
+                i, dst, off, m, tag, fut = staged.popleft()
+                fut.result()
+                dst[off:off + m].copy_(p.slots[i][:m], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(p.stream)
+                events[i] = ev
+                if on_chunk is not None:
+                    on_chunk(tag, off + m, ev)
+            for c, (src, dst, off, m, tag) in enumerate(tasks):
+                i = c % SLOTS
+                while any(s_[0] == i for s_ in staged):            # the slot still waits for its own DMA to be issued
+                    issue()
+                if events[i] is not None:
+                    events[i].synchronize()                        # its previous DMA has read the slot
+                staged.append((i, dst, off, m, tag, p.pool.submit(np.copyto, p.views[i][:m], src[off:off + m])))
+                while len(staged) > SLOTS - 2:
+                    issue()
+            while staged:
+                issue()
+        if join:
+            cur.wait_stream(p.stream)
+        for ev in events:                                          # the slots are free again when this call returns
+            if ev is not None:
+                ev.synchronize()
 
 
 def to_device(arr, dev):
@@ -50,36 +104,7 @@ def to_device(arr, dev):
     flat = a.reshape(-1).view(np.uint8)
     n = flat.size
     dst = torch.empty(n, dtype=torch.uint8, device=dev)
-    p = _pipe(dev)
-    with p.lock:
-        cur = torch.cuda.current_stream(dev)
-        p.stream.wait_stream(cur)                                  # `dst` belongs to the current stream's allocator history
-        events = [None] * SLOTS
-        staged = deque()
-        with torch.cuda.stream(p.stream):
-            def issue():
-                i, off, m, fut = staged.popleft()
-                fut.result()
-                dst[off:off + m].copy_(p.slots[i][:m], non_blocking=True)
-                ev = torch.cuda.Event()
-                ev.record(p.stream)
-                events[i] = ev
-            for c, off in enumerate(range(0, n, CHUNK)):
-                i = c % SLOTS
-                while any(s[0] == i for s in staged):              # the slot still waits for its own DMA to be issued
-                    issue()
-                if events[i] is not None:
-                    events[i].synchronize()                        # its previous DMA has read the slot
-                m = min(CHUNK, n - off)
-                staged.append((i, off, m, p.pool.submit(np.copyto, p.views[i][:m], flat[off:off + m])))
-                while len(staged) > SLOTS - 2:
-                    issue()
-            while staged:
-                issue()
-        cur.wait_stream(p.stream)
-        for ev in events:                                          # the slots are free again when this call returns
-            if ev is not None:
-                ev.synchronize()
+    upload_tasks(((flat, dst, off, min(CHUNK, n - off), None) for off in range(0, n, CHUNK)), dev)
     return dst.view(torch.from_numpy(a[:0].reshape(-1)).dtype).reshape(a.shape)
 
 

@@ -28,6 +28,7 @@ struct StitchArgs {
     float alpha_t;                // 'Rate': float32(rate + 1e-10), the constant alpha plane of imgT
     double ramp_den;              // 'Gradient': w + h of imgT; alpha(x, y) = float32((x + y) / (w + h) * 0.5)
     float alpha_q_in, alpha_q_out;  // canvas alpha inside / outside the imgQ rectangle (float32)
+    int row_begin, row_end;       // canvas rows this launch produces (rwh_stitch_panorama_rows)
 };
 
 // One RGB texel as a dword: an unaligned 4-byte load (3 bytes used) unless that would step past the image's last byte.
@@ -115,8 +116,8 @@ constexpr int ST_PX = 4;
 template <bool BLEND>
 __global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
     const int cx0 = (blockIdx.x * 64 + (threadIdx.x & 63)) * ST_PX;
-    const int cy = blockIdx.y * 4 + (threadIdx.x >> 6);
-    if (cx0 >= a.fw || cy >= a.fh) return;
+    const int cy = a.row_begin + blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (cx0 >= a.fw || cy >= a.row_end) return;
     const size_t t_bytes = (size_t)a.t_h * a.t_w * 3, q_bytes = (size_t)a.q_h * a.q_w * 3;
     unsigned char* out = a.dst + ((size_t)cy * a.fw + cx0) * 3;
     uint32_t px[ST_PX];
@@ -135,19 +136,35 @@ __global__ __launch_bounds__(256) void stitch_kernel(const StitchArgs a) {
 
 }  // namespace rwh
 
+extern "C" int rwh_stitch_panorama_rows(const void* d_img_t, int t_h, int t_w, const void* d_img_q, int q_h, int q_w,
+                                        const double* inv_h, int grid_x0, int grid_y0, int warp_w, int warp_h,
+                                        int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
+                                        int blend, double rate, void* d_canvas, int row_begin, int row_end, unsigned flags, void* stream);
+
 extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const void* d_img_q, int q_h, int q_w,
                                    const double* inv_h, int grid_x0, int grid_y0, int warp_w, int warp_h,
                                    int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
                                    int blend, double rate, void* d_canvas, unsigned flags, void* stream) {
+    return rwh_stitch_panorama_rows(d_img_t, t_h, t_w, d_img_q, q_h, q_w, inv_h, grid_x0, grid_y0, warp_w, warp_h, tsx, tsy, qsx, qsy,
+                                    canvas_h, canvas_w, blend, rate, d_canvas, 0, canvas_h, flags, stream);
+}
+
+extern "C" int rwh_stitch_panorama_rows(const void* d_img_t, int t_h, int t_w, const void* d_img_q, int q_h, int q_w,
+                                        const double* inv_h, int grid_x0, int grid_y0, int warp_w, int warp_h,
+                                        int tsx, int tsy, int qsx, int qsy, int canvas_h, int canvas_w,
+                                        int blend, double rate, void* d_canvas, int row_begin, int row_end, unsigned flags, void* stream) {
     using namespace rwh;
     if (!d_img_t || !d_img_q || !d_canvas || !inv_h) return RWH_E_INVALID;
+    if (row_begin < 0 || row_end > canvas_h || row_begin > row_end) return RWH_E_INVALID;
+    const bool whole = row_begin == 0 && row_end == canvas_h;
     if (t_h < 2 || t_w < 2 || q_h <= 0 || q_w <= 0 || warp_w <= 0 || warp_h <= 0 || canvas_h <= 0 || canvas_w <= 0) return RWH_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
     if (flags & RWH_WARP_ZERO_ORIGIN) {
         if (hipMemsetAsync(const_cast<void*>(d_img_t), 0, 3, s) != hipSuccess) return RWH_E_LAUNCH;
     }
     if (blend < 0 || blend > 2) return RWH_E_INVALID;
-    if ((flags & RWH_STITCH_FAST) && blend != 2) {   // the staged compositor carries constant weights: no ramp
+    if (row_begin == row_end) return RWH_OK;
+    if ((flags & RWH_STITCH_FAST) && blend != 2 && whole) {   // the staged compositor carries constant weights: no ramp (whole canvases only)
         // the reference's float32 alphas (see below), then the two weight pairs of the mean in float64 -> float32
         const double ta = (double)(float)(rate + 1e-10), qa_in = (double)(float)(1 + 1e-10 - rate), qa_out = (double)(float)1e-10;
         CompArgs c;
@@ -168,13 +185,14 @@ extern "C" int rwh_stitch_panorama(const void* d_img_t, int t_h, int t_w, const 
     a.t_h = t_h; a.t_w = t_w; a.q_h = q_h; a.q_w = q_w; a.fh = canvas_h; a.fw = canvas_w;
     a.tsx = tsx; a.tsy = tsy; a.wt = warp_w; a.ht = warp_h; a.gx0 = grid_x0; a.gy0 = grid_y0; a.qsx = qsx; a.qsy = qsy;
     a.blend = blend;
+    a.row_begin = row_begin; a.row_end = row_end;
     a.ramp_den = (double)(t_w + t_h);
     // the reference's Python-float arithmetic, then the float32 storage of its arrays
     a.alpha_t = (float)(rate + 1e-10);                 // addAlpha: rate += 1e-10; imgn[:, :, c] = rate   (float32 array)
     a.alpha_q_in = blend == 2 ? 1.0f                   // imgn[q-rect, 3] = 1                                 (homography.py:329)
                               : (float)(1 + 1e-10 - rate);   // imgn[q-rect, 3] = 1 + 1e-10 - blendrate       (float32 array)
     a.alpha_q_out = (float)1e-10;                      // imgn[:, :, 3] += 1e-10 on a float32 zero
-    const dim3 grid((canvas_w + 64 * ST_PX - 1) / (64 * ST_PX), (canvas_h + 3) / 4), block(256);
+    const dim3 grid((canvas_w + 64 * ST_PX - 1) / (64 * ST_PX), (row_end - row_begin + 3) / 4), block(256);
     if (blend) hipLaunchKernelGGL(stitch_kernel<true>, grid, block, 0, s, a);
     else hipLaunchKernelGGL(stitch_kernel<false>, grid, block, 0, s, a);
     return check_launch();

@@ -391,6 +391,20 @@ def stitch_panorama(img_t, img_q, inv_h, grid_origin, warp_wh, t_origin, q_origi
     return out
 
 
+def stitch_panorama_rows(img_t, img_q, inv_h, grid_origin, warp_wh, t_origin, q_origin, out, rows, blend, rate, zero_origin=False):
+    """Canvas rows [rows[0], rows[1]) of the exact compositor into `out` ([fh, fw, 3] uint8 on the device): rwh_stitch_panorama_rows,
+    on torch's current stream."""
+    lib = _lib.load()
+    _dev_check(img_t, img_q, out)
+    fh, fw = int(out.shape[0]), int(out.shape[1])
+    ih = np.ascontiguousarray(inv_h, dtype=np.float64).reshape(9)
+    check(lib.rwh_stitch_panorama_rows(_ptr(img_t), img_t.shape[0], img_t.shape[1], _ptr(img_q), img_q.shape[0], img_q.shape[1],
+                                       ih.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), int(grid_origin[0]), int(grid_origin[1]),
+                                       int(warp_wh[0]), int(warp_wh[1]), int(t_origin[0]), int(t_origin[1]), int(q_origin[0]),
+                                       int(q_origin[1]), fh, fw, int(blend), float(rate), _ptr(out), int(rows[0]), int(rows[1]),
+                                       RWH_WARP_ZERO_ORIGIN if zero_origin else 0, _lib.stream_ptr()), "rwh_stitch_panorama_rows")
+
+
 def decode_best(best_words, k_total):
     """Unpack the two argmax words (host ints) -> (winner_index, count, early_exit).
     Word 1 (first index reaching `need`) takes precedence, like the reference's

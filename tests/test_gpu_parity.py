@@ -1934,6 +1934,43 @@ def test_ransac_run_near_singular_inverse_vs_reference(gpu):
             assert np.array_equal(e, np.sqrt(np.sum(dlt * dlt, axis=0)), equal_nan=True), t
 
 
+def test_stitch_pipelined_equals_plain(gpu, auto_mode):
+    """stitchPanorama from host arrays: the pipelined form (uploads interleaved in the order the row tiles need them, tiles
+    composed by rwh_stitch_panorama_rows as their rows arrive, finished tiles sent down between the upload chunks) returns
+    the plain form's canvas bit for bit -- every canvas-geometry branch, every blending mode, a strong perspective whose tiles
+    need rows of imgT far from their own, the horizon inside the canvas -- and leaves the caller's arrays the same way."""
+    import contextlib
+    import io
+    import homography as hg
+    impl = auto_mode
+    rng = np.random.default_rng(21)
+    Q = rng.integers(1, 256, (700, 900, 3), dtype=np.uint8)
+    T = rng.integers(1, 256, (640, 1000, 3), dtype=np.uint8)
+    P = np.array([[1.0, 0.02, 0], [0.015, 0.98, 0], [1e-5, 2e-5, 1.0]])
+
+    def shift(tx, ty, M=P):
+        S = np.eye(3); S[0, 2] = tx; S[1, 2] = ty
+        return S @ M
+    strong = np.array([[0.8, 0.3, 0], [-0.25, 0.9, 0], [4e-4, -2e-4, 1.0]])
+    Hm = [shift(-300.3, -200.6), shift(-250.2, 310.4), shift(420.5, -150.3), shift(380.7, 290.2), shift(40.4, 30.3), shift(1500.2, 40.1),
+          shift(30.3, -900.7), shift(200.1, 100.2, strong), shift(-100.1, 50.2, strong)]
+    old = impl.PIPELINE_MIN_BYTES
+    try:
+        for hi, H in enumerate(Hm):
+            for blending in (False, "Rate", "Gradient"):
+                outs, afters = [], []
+                for pipe in (None, 1 << 16):
+                    impl.PIPELINE_MIN_BYTES = pipe
+                    t_in, q_in = T.copy(), Q.copy()
+                    with contextlib.redirect_stdout(io.StringIO()):
+                        outs.append(hg.stitchPanorama(q_in, t_in, H, blending=blending, blendrate=0.3))
+                    afters.append((t_in, q_in))
+                assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]), (hi, blending)
+                assert np.array_equal(afters[0][0], afters[1][0]) and np.array_equal(afters[0][1], afters[1][1]), (hi, blending)
+    finally:
+        impl.PIPELINE_MIN_BYTES = old
+
+
 def test_ransac_run_edge_cases_vs_reference(gpu):
     """g14 (written by the unmodified reference): the corners of RANSAC.run's input space -- one to four correspondences, none,
     k = 0 / 1, thresholds of 0, below 0 and huge, d of 0 and beyond the number of points, n < 4 and n > M, all points equal,
