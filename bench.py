@@ -663,7 +663,7 @@ def _config4_leg(backend):
             "stitch_from_host_arrays_ms": round(t_host * 1e3, 1),
             "note": "RANSAC.run incl. numpy sampling, uploads, readback, the host SVD settle step and the host refit; stitch = "
                     "compositor kernel on resident tensors (tensors in: the fast kernels; *_resident_ms = wall clock per Python call, *_gpu_ms = HIP events); from host arrays (exact float64 "
-                    "kernel) adds 2 x 134 MB up + canvas down over PCIe (page-locked staging ring + host copy threads up, DMA into a page-locked result down: _xfer.py)"}
+                    "kernel) adds 2 x 134 MB up + canvas down over PCIe (page-locked staging ring + host copy threads; uploads, composition by row tiles and the download overlapped: homography._stitch_pipelined)"}
 
 
 # ------------------------------------------------------------------------------------------------------------------
