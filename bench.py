@@ -648,7 +648,7 @@ def _config4_leg(backend):
         res[mode] = (time.perf_counter() - t0) / 20           # wall clock per Python call (host geometry, allocation, launch)
         res_ev[mode] = ev0.elapsed_time(ev1) / 20             # GPU time per call by HIP events on the launch stream
     t_host = 1e9
-    for _ in range(4):      # the first two calls page-lock the staging ring and the two result blocks (_xfer); then steady state
+    for _ in range(7):      # the first two calls page-lock the staging ring and the two result blocks (_xfer); then steady state
         A8c = A8.copy()     # (stitchPanorama blanks texel (0,0) of the caller's imgT like the reference: hand it a copy, untimed)
         t0 = time.perf_counter()
         out_np = hg.stitchPanorama(B8, A8c, H8)
