@@ -158,13 +158,18 @@ def _to_device(img):
         if t.dtype not in (torch.uint8, torch.float32):
             t = t.to(torch.float32)
         return t.contiguous(), False, None
+    src, np_dtype = _host_src(img)
+    return _xfer.to_device(src, dev), True, np_dtype
+
+
+def _host_src(img):
+    """numpy image -> (the uint8 / float32 array the kernels read, the caller's dtype)."""
     a = np.asarray(img)
     if a.ndim != 3:
         raise ValueError("not enough values to unpack (expected 3, got %d)" % a.ndim)  # img.shape unpack
     if a.shape[2] not in (3, 4):
         raise IndexError("index out of bounds: the warp supports 3 or 4 channels")
-    src = a if a.dtype in (np.uint8, np.float32) else a.astype(np.float32)
-    return _xfer.to_device(src, dev), True, a.dtype
+    return (a if a.dtype in (np.uint8, np.float32) else a.astype(np.float32)), a.dtype
 
 
 def _warp(img, H, grid, bound_hw, convert, u8_out):
@@ -173,6 +178,25 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
     if convert not in kernels.INTERP:
         raise KeyError(convert)  # convertfunc[convert], homography.py:179 / 208
     inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))  # homography.py:172 / 203 (raises LinAlgError)
+    if not _is_tensor(img) and PIPELINE_MIN_BYTES is not None:
+        # a large host array through the exact kernels: upload, kernel by output-row tiles and download overlapped (_warp_pipelined)
+        a, np_dtype = _host_src(img)
+        exact = True if EXACT is None else bool(EXACT)
+        t_dtype = torch.uint8 if a.dtype == np.uint8 else torch.float32
+        out_dtype = t_dtype if convert == "nn" else (torch.uint8 if u8_out else torch.float64 if exact else torch.float32)
+        out_bytes = grid.out_h * grid.out_w * a.shape[2] * torch.empty(0, dtype=out_dtype).element_size()
+        if a.shape[0] >= 3 and a.shape[1] >= 3 and a.nbytes + out_bytes >= PIPELINE_MIN_BYTES * PIPELINE_WARP_FACTOR and grid.out_h >= 64:
+            dev = _lib.require_gpu()
+            a = np.ascontiguousarray(a)
+            flag = kernels.warp_index_check(a.shape[:2], inv_h, grid, bound_hw, convert, dev)
+            res = _warp_pipelined(a, inv_h, grid, bound_hw, convert, out_dtype, exact, dev)
+            _blank_origin(img)
+            bits = int(flag.item())
+            if bits:
+                kernels.raise_like_reference(bits, a.shape[:2])
+            if convert == "nn":
+                return res if res.dtype == np_dtype else res.astype(np_dtype)
+            return res if (u8_out or res.dtype == np.float64) else res.astype(np.float64)
     src, was_numpy, np_dtype = _to_device(img)
     true_hw = (int(src.shape[0]), int(src.shape[1]))
     if true_hw[0] < 3 or true_hw[1] < 3:      # the kernels want 3 x 3 texels at least: zero rows / columns beyond the bounds, which
@@ -420,84 +444,77 @@ def _stitch_host(imgQ, imgT, H, blending, blendrate):
     return imgn
 
 
-PIPELINE_MIN_BYTES = 48 << 20      # host arrays: below this (both images + canvas) the plain upload / compose / download
+# host arrays: below this many bytes (inputs + result) the plain upload / kernel / download (None: never pipelined).  Measured: a stitch
+# gains from ~90 MB on (two 4K frames 3.0 -> 2.8 ms, two 12 MP photographs 4.2 -> 3.8, two 8K frames 9.4 -> 6.4, config 4's 8192 x 5464 pair
+# 11.4 -> 7.7); a single warp only from 8K frames on (4.7 -> 3.8 ms; 4K: 1.5 ms plain against 2.4 -- two dozen tiles cost more than they hide)
+PIPELINE_MIN_BYTES = 64 << 20
+PIPELINE_WARP_FACTOR = 2.5         # a single warp is pipelined from PIPELINE_MIN_BYTES x this on
 
 
-def _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh, fw, mode, blendrate, dev):
-    """stitchPanorama from host arrays with the three PCIe legs overlapped: the canvas is composed by row tiles
-    (rwh_stitch_panorama_rows, the exact kernel), a tile as soon as the rows of imgT it samples (the tile's corners mapped through
-    inv(H): a projective map takes its extremes over a convex region at the vertices) and the rows of imgQ it covers have
-    arrived -- the two images go up interleaved, in the order the tiles need them --, and each finished tile goes down to a
-    page-locked host block in 8 MB pieces issued between the upload chunks (this runtime overlaps the two directions only
-    when their copies are enqueued alternately: two 256 MB copies on two streams take 9.4 ms, the same bytes in alternating
-    8 MB pieces 5.9 ms).  -> the canvas as a host array (page-locked, like _xfer.to_host's)."""
+def _rows_needed(ih, xs, y_lo, y_hi, src_h):
+    """Source rows [0, n) a warp samples for output rows y_lo .. y_hi (grid coordinates) and columns xs[0] .. xs[1]: the four
+    corners through inv(H) -- a projective map with W > 0 on a convex region takes its extremes at the vertices -- plus the
+    +1 tap and a margin; all rows when the horizon touches the region."""
+    X = np.array([xs[0], xs[1], xs[0], xs[1]], dtype=np.float64)
+    Y = np.array([y_lo, y_lo, y_hi, y_hi], dtype=np.float64)
+    W = ih[2, 0] * X + ih[2, 1] * Y + ih[2, 2]
+    if not (W > 0).all():
+        return src_h
+    ymax = float(np.max((ih[1, 0] * X + ih[1, 1] * Y + ih[1, 2]) / W))
+    return src_h if not np.isfinite(ymax) else int(min(src_h, max(0.0, np.floor(ymax) + 3)))
+
+
+def _pipeline(dev, uploads, need, bounds, compose, result, host):
+    """The three PCIe legs of a host-array call overlapped (full duplex).  `uploads`: {tag: (flat uint8 host array, flat uint8
+    device tensor)}; `need`[i]: {tag: bytes of that array row tile i reads}; `bounds`: the tiles' row boundaries in `result`
+    (a device tensor whose rows go down into `host`, a page-locked tensor of the same shape); compose(i, r0, r1) enqueues tile
+    i's kernel on the current stream.  The arrays go up interleaved in the order the tiles need them, a tile is composed as
+    soon as its bytes have landed, finished tiles go down in 8 MB pieces issued BETWEEN the upload chunks: this runtime
+    overlaps the two directions only when their copies alternate in the queues (two 256 MB copies on two streams: 9.4 ms; the
+    same bytes as alternating 8 MB pieces: 5.9 ms)."""
     import torch
     from collections import deque
-    tT = np.ascontiguousarray(imgT).reshape(-1).view(np.uint8)
-    tQ = np.ascontiguousarray(imgQ).reshape(-1).view(np.uint8)
-    h, w = int(imgT.shape[0]), int(imgT.shape[1])
-    hq, wq = int(imgQ.shape[0]), int(imgQ.shape[1])
     cur = torch.cuda.current_stream(dev)
     comp, down = _xfer.side_stream(dev, "compose"), _xfer.side_stream(dev, "download")
-    canvas = torch.empty((fh, fw, 3), dtype=torch.uint8, device=dev)
-    host = torch.empty((fh, fw, 3), dtype=torch.uint8, pin_memory=True)
-    t_flat = torch.empty(tT.size, dtype=torch.uint8, device=dev)
-    q_flat = torch.empty(tQ.size, dtype=torch.uint8, device=dev)
-    t_dev, q_dev = t_flat.view(h, w, 3), q_flat.view(hq, wq, 3)
     comp.wait_stream(cur)
     down.wait_stream(cur)
-    nt = int(max(1, min(24, fh // 128)))
-    bounds = np.linspace(0, fh, nt + 1).astype(np.int64)
-    ih = np.asarray(inv_h, dtype=np.float64)
-    need = []                                   # per tile: bytes of imgT and of imgQ that must have arrived
-    for i in range(nt):
-        r0, r1 = int(bounds[i]), int(bounds[i + 1])
-        lo, hi = max(r0, tsy), min(r1, tsy + ht)
-        rows_t = 0
-        if lo < hi:
-            xs = np.array([mx, mx + wt - 1, mx, mx + wt - 1], dtype=np.float64)
-            ys = np.array([my + lo - tsy, my + lo - tsy, my + hi - 1 - tsy, my + hi - 1 - tsy], dtype=np.float64)
-            W = ih[2, 0] * xs + ih[2, 1] * ys + ih[2, 2]
-            if (W > 0).all():
-                ymax = float(np.max((ih[1, 0] * xs + ih[1, 1] * ys + ih[1, 2]) / W))
-                rows_t = h if not np.isfinite(ymax) else int(min(h, max(0.0, np.floor(ymax) + 3)))
-            else:
-                rows_t = h                      # the horizon crosses the tile: anything can be sampled
-        rows_q = int(max(0, min(hq, r1 - qsy))) if (r1 > qsy and r0 < qsy + hq) else 0
-        need.append([rows_t * w * 3, rows_q * wq * 3])
-    need[0][0] = max(need[0][0], 3)             # the first tile blanks texel (0,0) of imgT: behind the chunk that carries it
+    nt = len(bounds) - 1
+    size = {t: u[0].size for t, u in uploads.items()}
+    need = [{t: min(int(n.get(t, 0)), size[t]) for t in uploads} for n in need]
     for i in range(1, nt):                      # tiles launch in order: what an earlier tile needed has arrived
-        need[i][0] = max(need[i][0], need[i - 1][0]); need[i][1] = max(need[i][1], need[i - 1][1])
-    # upload order: for each tile in turn, whatever it still lacks of imgT, then of imgQ; the rest at the end
-    C = _xfer.CHUNK
-    tasks, sent = [], {"t": 0, "q": 0}
-    size = {"t": tT.size, "q": tQ.size}
-    src = {"t": (tT, t_flat), "q": (tQ, q_flat)}
+        for t in uploads:
+            need[i][t] = max(need[i][t], need[i - 1][t])
+    C = _xfer.CHUNK if max(size.values()) >= (64 << 20) else (2 << 20)      # finer pieces for single frames
+    tasks, sent = [], {t: 0 for t in uploads}
 
     def push(tag, upto):
-        while sent[tag] < min(upto, size[tag]):
+        while sent[tag] < upto:
             m = min(C, size[tag] - sent[tag])
-            tasks.append((src[tag][0], src[tag][1], sent[tag], m, tag))
+            tasks.append((uploads[tag][0], uploads[tag][1], sent[tag], m, tag))
             sent[tag] += m
     for i in range(nt):
-        push("t", need[i][0]); push("q", need[i][1])
-    push("t", size["t"]); push("q", size["q"])
-    state = {"t": 0, "q": 0, "t_ev": None, "q_ev": None, "next": 0}
-    pieces = deque()                            # (row0, row1, event of the tile's compose launch) still to go down
+        for t in uploads:
+            push(t, need[i][t])
+    for t in uploads:
+        push(t, size[t])
+    have = {t: 0 for t in uploads}
+    last_ev = {t: None for t in uploads}
+    state = {"next": 0}
+    pieces = deque()                            # (row0, row1, event of the tile's kernel) still to go down
+    row_bytes = result[0].numel() * result.element_size() if result.shape[0] else 1
 
     def launch_ready():
-        while state["next"] < nt and state["t"] >= min(need[state["next"]][0], size["t"]) and state["q"] >= min(need[state["next"]][1], size["q"]):
+        while state["next"] < nt and all(have[t] >= need[state["next"]][t] for t in uploads):
             i = state["next"]
             r0, r1 = int(bounds[i]), int(bounds[i + 1])
             with torch.cuda.stream(comp):
-                for ev in (state["t_ev"], state["q_ev"]):
+                for ev in last_ev.values():
                     if ev is not None:
                         comp.wait_event(ev)
-                kernels.stitch_panorama_rows(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), canvas, (r0, r1), mode, blendrate,
-                                             zero_origin=(i == 0))
+                compose(i, r0, r1)
                 done = torch.cuda.Event()
                 done.record(comp)
-            step = max(1, C // (fw * 3))
+            step = max(1, C // row_bytes)
             for a0 in range(r0, r1, step):
                 pieces.append((a0, min(r1, a0 + step), done))
             state["next"] += 1
@@ -507,12 +524,12 @@ def _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh,
             while n > 0 and pieces:
                 a0, a1, done = pieces.popleft()
                 down.wait_event(done)
-                host[a0:a1].copy_(canvas[a0:a1], non_blocking=True)
+                host[a0:a1].copy_(result[a0:a1], non_blocking=True)
                 n -= 1
 
     def got(tag, nbytes, ev):
-        state[tag] = nbytes
-        state[tag + "_ev"] = ev
+        have[tag] = nbytes
+        last_ev[tag] = ev
         launch_ready()
         send_down(2)                            # two pieces down per chunk up: the directions alternate in the DMA queues
     _xfer.upload_tasks(tasks, dev, on_chunk=got, join=False)
@@ -522,6 +539,65 @@ def _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh,
     cur.wait_stream(comp)
     cur.wait_stream(down)
     return host.numpy()
+
+
+def _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh, fw, mode, blendrate, dev):
+    """stitchPanorama from host arrays through `_pipeline`: the canvas by row tiles (rwh_stitch_panorama_rows, the exact kernel), a
+    tile as soon as the rows of imgT it samples and the rows of imgQ it covers have arrived.  -> the canvas as a host array
+    (page-locked, like _xfer.to_host's)."""
+    import torch
+    tT = np.ascontiguousarray(imgT).reshape(-1).view(np.uint8)
+    tQ = np.ascontiguousarray(imgQ).reshape(-1).view(np.uint8)
+    h, w = int(imgT.shape[0]), int(imgT.shape[1])
+    hq, wq = int(imgQ.shape[0]), int(imgQ.shape[1])
+    canvas = torch.empty((fh, fw, 3), dtype=torch.uint8, device=dev)
+    host = torch.empty((fh, fw, 3), dtype=torch.uint8, pin_memory=True)
+    t_flat = torch.empty(tT.size, dtype=torch.uint8, device=dev)
+    q_flat = torch.empty(tQ.size, dtype=torch.uint8, device=dev)
+    t_dev, q_dev = t_flat.view(h, w, 3), q_flat.view(hq, wq, 3)
+    nt = int(max(1, min(24, fh // 128)))
+    bounds = np.linspace(0, fh, nt + 1).astype(np.int64)
+    ih = np.asarray(inv_h, dtype=np.float64)
+    need = []
+    for i in range(nt):
+        r0, r1 = int(bounds[i]), int(bounds[i + 1])
+        lo, hi = max(r0, tsy), min(r1, tsy + ht)
+        rows_t = _rows_needed(ih, (mx, mx + wt - 1), my + lo - tsy, my + hi - 1 - tsy, h) if lo < hi else 0
+        rows_q = int(max(0, min(hq, r1 - qsy))) if (r1 > qsy and r0 < qsy + hq) else 0
+        need.append({"t": rows_t * w * 3, "q": rows_q * wq * 3})
+    need[0]["t"] = max(need[0]["t"], 3)         # the first tile blanks texel (0,0) of imgT: behind the chunk that carries it
+
+    def compose(i, r0, r1):
+        kernels.stitch_panorama_rows(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), canvas, (r0, r1), mode, blendrate,
+                                     zero_origin=(i == 0))
+    return _pipeline(dev, {"t": (tT, t_flat), "q": (tQ, q_flat)}, need, bounds, compose, canvas, host)
+
+
+def _warp_pipelined(a, inv_h, grid, bound_hw, convert, out_dtype, exact, dev):
+    """One warp from a host array through `_pipeline`: output row tiles (rwh_warp_backward's row_begin / row_end), a tile as soon
+    as the source rows it samples have arrived.  a: contiguous uint8 / float32 H x W x C host array.  -> host array."""
+    import torch
+    flat = a.reshape(-1).view(np.uint8)
+    h, w, c = (int(v) for v in a.shape)
+    t_dtype = torch.uint8 if a.dtype == np.uint8 else torch.float32
+    s_flat = torch.empty(flat.size, dtype=torch.uint8, device=dev)
+    src = s_flat.view(t_dtype).view(h, w, c)
+    oh, ow = grid.out_h, grid.out_w
+    result = torch.empty((oh, ow, c), dtype=out_dtype, device=dev)
+    host = torch.empty((oh, ow, c), dtype=out_dtype, pin_memory=True)
+    nt = int(max(1, min(24, oh // 64)))
+    bounds = np.linspace(0, oh, nt + 1).astype(np.int64)
+    ih = np.asarray(inv_h, dtype=np.float64)
+    row_b = w * c * a.itemsize
+
+    def gy(r):
+        return grid.y_last if r == oh - 1 else grid.y0 + r * grid.step_y
+    need = [{"s": _rows_needed(ih, (grid.x0, grid.x_last), gy(int(bounds[i])), gy(int(bounds[i + 1]) - 1), h) * row_b} for i in range(nt)]
+    need[0]["s"] = max(need[0]["s"], c * a.itemsize)      # the first tile blanks texel (0,0)
+
+    def compose(i, r0, r1):
+        kernels.warp_backward(src, inv_h, grid, bound_hw, convert, out_dtype, zero_origin=(i == 0), rows=(r0, r1), out=result[r0:r1], exact=exact)
+    return _pipeline(dev, {"s": (flat, s_flat)}, need, bounds, compose, result, host)
 
 
 def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0.2):

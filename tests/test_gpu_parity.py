@@ -1954,7 +1954,8 @@ def test_stitch_pipelined_equals_plain(gpu, auto_mode):
     strong = np.array([[0.8, 0.3, 0], [-0.25, 0.9, 0], [4e-4, -2e-4, 1.0]])
     Hm = [shift(-300.3, -200.6), shift(-250.2, 310.4), shift(420.5, -150.3), shift(380.7, 290.2), shift(40.4, 30.3), shift(1500.2, 40.1),
           shift(30.3, -900.7), shift(200.1, 100.2, strong), shift(-100.1, 50.2, strong)]
-    old = impl.PIPELINE_MIN_BYTES
+    old, old_f = impl.PIPELINE_MIN_BYTES, impl.PIPELINE_WARP_FACTOR
+    impl.PIPELINE_WARP_FACTOR = 1.0
     try:
         for hi, H in enumerate(Hm):
             for blending in (False, "Rate", "Gradient"):
@@ -1967,8 +1968,37 @@ def test_stitch_pipelined_equals_plain(gpu, auto_mode):
                     afters.append((t_in, q_in))
                 assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1]), (hi, blending)
                 assert np.array_equal(afters[0][0], afters[1][0]) and np.array_equal(afters[0][1], afters[1][1]), (hi, blending)
+        # the single warps take the same pipeline (output-row tiles of rwh_warp_backward): every entry point, both interpolators,
+        # uint8 RGB and float32 RGBA images, the exact and the fast kernels, a strong perspective, a horizon inside the grid
+        T4 = rng.uniform(0, 255, (640, 1000, 4)).astype(np.float32)
+        horizon = np.linalg.inv(np.array([[1.0, 0.02, 3.0], [0.01, 1.0, 2.0], [-3.1e-3, -2.3e-3, 1.0]]))
+        for exact_mode in (None, False):
+            impl.EXACT = exact_mode
+            for hi, H in enumerate([shift(40.4, 30.3), shift(-300.3, 200.6, strong), np.array([[0.6, 0.05, 10.0], [0.02, 0.7, 5.0], [1e-5, 0, 1.0]]), horizon]):
+                for conv in ("nn", "bilinear"):
+                    for img in (T, T4):
+                        for fn, args in ((hg.wrapPerspective, (H,)), (hg.wrapPerspectiveScan, (H, (500, 700))), (hg.transformImageH, (H,))):
+                            kw = {"method": conv} if fn is hg.transformImageH else {"convert": conv}
+                            outs, afters = [], []
+                            for pipe in (None, 1 << 16):
+                                impl.PIPELINE_MIN_BYTES = pipe
+                                a_in = img.copy()
+                                try:
+                                    with np.errstate(all="ignore"):
+                                        r = fn(a_in, *args, **kw)
+                                    outs.append(r)
+                                except Exception as e:      # noqa: BLE001
+                                    outs.append(type(e).__name__)
+                                afters.append(a_in)
+                            if isinstance(outs[0], str) or isinstance(outs[1], str):
+                                assert outs[0] == outs[1], (exact_mode, hi, conv, img.dtype, fn.__name__, outs)
+                            else:
+                                assert outs[0][0].dtype == outs[1][0].dtype and np.array_equal(outs[0][0], outs[1][0], equal_nan=True) and \
+                                    outs[0][1:] == outs[1][1:], (exact_mode, hi, conv, img.dtype, fn.__name__)
+                            assert np.array_equal(afters[0], afters[1]), (exact_mode, hi, conv, fn.__name__)
     finally:
-        impl.PIPELINE_MIN_BYTES = old
+        impl.PIPELINE_MIN_BYTES, impl.PIPELINE_WARP_FACTOR = old, old_f
+        impl.EXACT = None
 
 
 def test_ransac_run_edge_cases_vs_reference(gpu):
