@@ -85,10 +85,10 @@ for case in range(cases):
             want.append(outcome(orc.ransac_run, A32.T, B32.T, th=th, d=d, n=n, k=k, method=m))
             probs.append([A32.T, B32.T])
         o2, got = outcome(rmod.run_batch, probs, th=th, d=d, n=n, k=k, method=m, idx=tables)
-        if any(w_[0] != "ok" for w_ in want):
-            ok = o2 != "ok"                 # one failing problem fails the call, as P reference runs in a row would
-        else:
-            ok = o2 == "ok" and all(int(g_[2]) == int(w_[1][2]) and np.array_equal(g_[1][0], w_[1][1][0]) for g_, w_ in zip(got, want))
+        # a problem whose winner has too few inliers for the refit: the reference raises AssertionError (ransac.py:38), run_batch returns
+        # finalModel None for it (its docstring) and goes on with the others
+        ok = o2 == "ok" and all((g_[0] is None) if w_[0] == "AssertionError" else
+                                (w_[0] == "ok" and int(g_[2]) == int(w_[1][2]) and np.array_equal(g_[1][0], w_[1][1][0])) for g_, w_ in zip(got, want))
         if not ok:
             bad += 1
             print("case %d run_batch P %d k %d %s th %g d %d: oracle %s, product %s" % (case, P, k, m, th, d, [w_[0] for w_ in want], o2), flush=True)
