@@ -56,10 +56,12 @@ RWH_API const char* rwh_strerror(int code);
  * (value 0 = back to the library's own choice).  RWH_TUNE_WARP_SHAPE: log2 of the fast bilinear kernel's patch width (5, 6, 7; 13, 14 = 32 x 16 / 64 x 8 patches staged by halves, the minification form of the uint8 RGB kernel); RWH_TUNE_SCORE_HPW:
  * hypotheses per wavefront of the scorer (1..64); RWH_TUNE_SCORE_EXACT: 1 = the scorer skips its reciprocal-based
  * filter and runs the two IEEE divisions for every pair (the filter only ever decides pairs that clear the threshold
- * by a proven error band, so counts and masks are the same either way).  Results never depend on any of them
- * (tests/test_gpu_parity.py).
+ * by a proven error band, so counts and masks are the same either way); RWH_TUNE_WARP_FRAMES (round 4): frames per block of
+ * the multi-frame form of the uint8 RGB bilinear kernel (one homography, batch >= 2: warp_rgb8_fast8m, a lab kernel that shares
+ * a patch's coordinate / weight arithmetic between the frames of a batch) -- 0 / 1 = one frame per block (the product kernel),
+ * 2..64 = that many.  Results never depend on any of them (tests/test_gpu_parity.py).
  */
-enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1, RWH_TUNE_SCORE_EXACT = 2 };
+enum { RWH_TUNE_WARP_SHAPE = 0, RWH_TUNE_SCORE_HPW = 1, RWH_TUNE_SCORE_EXACT = 2, RWH_TUNE_WARP_FRAMES = 3 };
 RWH_API int rwh_lab_tune(int knob, int value);
 
 /*

@@ -20,7 +20,7 @@ RWH_STITCH_FAST = 4
 RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND = 1, 2, 4
 RWH_BATCH_DEVICE_SAMPLING = 1
 RWH_BATCH_EARLY_STOP = 2
-RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT = 0, 1, 2
+RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT, RWH_TUNE_WARP_FRAMES = 0, 1, 2, 3
 
 # every symbol include/rwh.h declares (tests check the library exports them all)
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",

@@ -6,6 +6,7 @@ namespace rwh {
 int g_force_warp_shape = 0;
 int g_force_score_hpw = 0;
 int g_score_exact_only = 0;
+int g_force_warp_frames = 0;
 }  // namespace rwh
 
 extern "C" int rwh_abi_version(void) { return RWH_ABI_VERSION; }
@@ -14,6 +15,7 @@ extern "C" int rwh_lab_tune(int knob, int value) {
     if (knob == RWH_TUNE_WARP_SHAPE && (value == 0 || (value >= 5 && value <= 7) || value == 13 || value == 14)) { rwh::g_force_warp_shape = value; return RWH_OK; }
     if (knob == RWH_TUNE_SCORE_HPW && value >= 0 && value <= 64) { rwh::g_force_score_hpw = value; return RWH_OK; }
     if (knob == RWH_TUNE_SCORE_EXACT && (value == 0 || value == 1)) { rwh::g_score_exact_only = value; return RWH_OK; }
+    if (knob == RWH_TUNE_WARP_FRAMES && value >= 0 && value <= 64) { rwh::g_force_warp_frames = value; return RWH_OK; }
     return RWH_E_INVALID;
 }
 

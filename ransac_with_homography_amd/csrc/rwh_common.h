@@ -23,7 +23,7 @@ struct __attribute__((packed)) pk4 { uint32_t a, b, c, d; };
 __device__ __forceinline__ pk2 ld8(const unsigned char* p) { pk2 v; __builtin_memcpy(&v, p, 8); return v; }
 __device__ __forceinline__ uint32_t ld4(const unsigned char* p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 
-extern int g_force_warp_shape, g_force_score_hpw, g_score_exact_only;   // rwh_api.hip (rwh_lab_tune)
+extern int g_force_warp_shape, g_force_score_hpw, g_score_exact_only, g_force_warp_frames;   // rwh_api.hip (rwh_lab_tune)
 
 inline int check_launch() {
     return hipGetLastError() == hipSuccess ? RWH_OK : RWH_E_LAUNCH;

@@ -555,6 +555,26 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
             hipLaunchKernelGGL(ck, dim3(8u * a.cpx), block, 0, s, a, *comp);
             return check_launch();
         }
+        // one homography, several frames, interior geometry shared by the frames of a block (warp_rgb8_fast8m): uint8 RGB bilinear
+        // whole-patch kernel only.  OFF unless rwh_lab_tune(RWH_TUNE_WARP_FRAMES, n >= 2) asks for n frames per block: the kernel
+        // halves the VALU work per frame (366 -> ~185 instructions per wave and frame) and is bit-identical, but same-box A/B
+        // (profiles/r04_lab_notes.txt) gives +3 % on 4K x 32, +2 % on 1080p x 512 and -3 % on 8K x 8 at its best setting (3-4
+        // frames): this warp is bound by the memory system's throughput on its access pattern, not by its arithmetic.
+        if (px8 && !nn && !custom && !halves && u8 && batch >= 2 && g_force_warp_frames >= 2) {
+            const int want = g_force_warp_frames;
+            const int F = want < batch ? want : batch;
+            const unsigned long long ntiles = (unsigned long long)a.tiles_x * a.tiles_y, groups = ((unsigned)batch + F - 1) / F;
+            const unsigned long long mnb = ntiles * groups;
+            const unsigned magic = div_magic((unsigned)ntiles, mnb);
+            if (mnb < (1ull << 31) / 8 && (ntiles == 1 || magic)) {
+                a.mf_frames = F; a.mf_batch = batch; a.ntiles = (unsigned)ntiles; a.ntiles_magic = magic;
+                a.mf_nblocks = (unsigned)mnb; a.mf_cpx = (a.mf_nblocks + 7u) / 8u;
+                if (plan_only("rwh::warp_rgb8_fast8m<%.0s%d>", "", shape)) return RWH_OK;
+                void (*mk)(const FastArgs) = shape == 7 ? warp_rgb8_fast8m<7> : shape == 6 ? warp_rgb8_fast8m<6> : warp_rgb8_fast8m<5>;
+                hipLaunchKernelGGL(mk, dim3(8u * a.mf_cpx), block, 0, s, a);
+                return check_launch();
+            }
+        }
         if (custom ? false : nn ? plan_only("rwh::warp_rgb8_nn<%.0s%d>", "", shape)
                           : !px8 ? plan_only("rwh::warp_rgb8_fast<%s>", u8 ? "unsigned char" : "float")
                           : halves ? plan_only("rwh::warp_rgb8_fast8h<%.0s%d>", "", shape)

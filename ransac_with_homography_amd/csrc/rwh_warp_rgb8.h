@@ -76,6 +76,9 @@ struct FastArgs {
     int group;                                           // free parameter of a tools/warp_lab custom kernel
     double gx0, gstep_x, gx_last, gy0, gstep_y, gy_last; // numpy.linspace output grid (nearest-neighbour kernel's exact formula)
     int out_h;
+    // multi-frame kernels (warp_rgb8_fast8m, round 4): one block = one 128 x 16 tile of mf_frames consecutive frames
+    int mf_frames, mf_batch;                             // frames per block, frames in the launch
+    unsigned mf_nblocks, mf_cpx, ntiles, ntiles_magic;   // blocks of the multi-frame grid (tile fastest), tiles per frame
 };
 
 __device__ __forceinline__ uint32_t hi32(double v) { return (uint32_t)(__double_as_longlong(v) >> 32); }
@@ -678,8 +681,18 @@ template <typename DstT, int LOG_PW> constexpr int f8_waves() {
 // slab.  A 16 x 16 half of a 32 x 16 patch fits the 40 x 38 window up to ~2.2x minification, where the whole patch stops
 // fitting at ~1.09x (64 x 8: 1.28x) and every wave used to gather.  The halves' corners are the run's own end pixels, so
 // footprint and taps agree about every floor() as they do for whole patches; a half that does not fit gathers.
-template <typename DstT, int LOG_PW, bool COMP = false, int CH = 3, bool HALVES = false>
-__device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, const CompArgs* cp = nullptr) {
+// the four waves' LDS slabs: one function-local array, so that two bodies inlined into one kernel (the multi-frame kernel
+// and its per-frame fallback) share it
+template <int SLAB_BYTES>
+__device__ __forceinline__ unsigned char* wave_slabs() {
+    __shared__ __attribute__((aligned(16))) unsigned char s[4 * SLAB_BYTES];
+    return s;
+}
+// ovr_logical >= 0: the (tile, image) this block works on, as the logical block index of a one-frame-per-block launch
+// (the multi-frame kernel hands its non-interior patches to this body frame by frame)
+template <typename DstT, int LOG_PW, bool COMP = false, int CH = 3, bool HALVES = false, bool EXT_SLAB = false>
+__device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, const CompArgs* cp = nullptr, const int ovr_logical = -1,
+                                           unsigned char* const slab_ext = nullptr, const int ovr_wave = -1) {
     static_assert(CH == 3 || (CH == 4 && !COMP && sizeof(DstT) == 1), "4 channels: uint8 RGBA in and out, no compositor");
     static_assert(!HALVES || (!COMP && sizeof(DstT) == 1), "halves: uint8 output, no compositor");
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
@@ -691,18 +704,19 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     // weight constants: RGB taps enter the blend as float16 halves (b * 2^-24), so the weights carry 2^24 (blend4)
     constexpr bool MX = CH == 3 && MIX_RGB;
     constexpr float WS = MX ? W_SCALE * MIX_S : W_SCALE, WO = MX ? W_ONE * MIX_S : W_ONE, WC = MX ? MIX_S : 1.0f;
-    __shared__ __attribute__((aligned(16))) unsigned char slab[4][SLAB];
+    unsigned char* slab0;
+    if constexpr (EXT_SLAB) slab0 = slab_ext; else slab0 = wave_slabs<SLAB>();     // (slab_ext: the calling kernel's own, at least as large)
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
     const unsigned b = blockIdx.x;
-    const unsigned logical = (b & 7u) * a.cpx + (b >> 3);   // XCD k walks logical blocks [k*cpx, (k+1)*cpx)
+    const unsigned logical = ovr_logical >= 0 ? (unsigned)ovr_logical : (b & 7u) * a.cpx + (b >> 3);   // XCD k walks logical blocks [k*cpx, (k+1)*cpx)
     const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;   // magic 0 <=> divisor 1
     const unsigned tx = logical - t * a.tiles_x;
     {   // a patch that owns nothing does nothing: a block past the grid, or a patch of the moved last tile of a ragged row
         // whose columns all belong to the tile on its left (out_w = 1921 leaves that tile ONE column).  (Folded into the one
         // early return on purpose: a second `return` further down -- e.g. for patches below the last row -- costs the
         // 64-VGPR uint8 kernel three spilled registers.)
-        const int w0 = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+        const int w0 = ovr_wave >= 0 ? ovr_wave : __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
         const int own_from = (int)tx * 128 - min((int)tx * 128, a.out_w - 128);
         if ((logical >= a.nblocks) | ((w0 % (128 / (1 << LOG_PW)) + 1) * (1 << LOG_PW) <= own_from)) return;
     }
@@ -710,7 +724,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const unsigned ty = t - img * a.tiles_y;
     const Coef& co = tab ? tab[img] : a.c;                  // uniform: scalar loads either way
     const unsigned img_mem = tab ? (unsigned)co.image : img;   // where the image lives in the batch
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pwave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));      // physical wave: owns LDS slab pwave
+    const int wave = ovr_wave >= 0 ? ovr_wave : pwave;                                   // which patch of the tile
     const int lane = threadIdx.x & 63;
     const int prow = lane / LPR, pq = lane % LPR;             // patch row, 4-pixel column group within a half row
     const int wave_x = (wave % WX) * PW, wave_y = (wave / WX) * PH;   // patch origin inside the 128 x 16 tile
@@ -868,7 +883,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     }
 
     // ---- staging loads go out now: lane -> (row srow of the pass, chunk scol), fixed for the kernel ---------------------
-    unsigned char* my = slab[wave];
+    unsigned char* my = slab0 + pwave * SLAB;
     using chunk_t = typename std::conditional<CH == 4, pk4, pk3>::type;   // 4 texels as they lie in memory: 12 or 16 bytes
     chunk_t v[Win::PASSES];
     // lanes outside the footprint (chunk >= C, or past the last full row of a pass) load nothing: the texture-address
@@ -903,7 +918,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         // footprint origin and the slab's own LDS offset go into one uniform
         // (the multiply-add is spelled in assembly: given __umul24, LLVM distributes the subtraction and emits a
         //  quarter-rate v_mul_lo_u32 per tap)
-        const uint32_t slab_off = (uint32_t)wave * (uint32_t)SLAB;
+        const uint32_t slab_off = (uint32_t)pwave * (uint32_t)SLAB;
         const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;   // uniform
 #pragma unroll
         for (int p = 0; p < Win::PASSES; ++p) {
@@ -935,8 +950,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 #ifdef RWH_ABL_NOLDS    // tools/warp_lab ablation hook (never defined in the product build)
                 a0[j] = lo; b0[j] = lo * 3u; a1[j] = lo * 5u; b1[j] = lo * 7u;
 #else
-                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo);
-                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo + lpitch);
+                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(slab0 + lo);
+                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(slab0 + lo + lpitch);
                 a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
 #endif
             }
@@ -1103,14 +1118,14 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const uint32_t slab_off = (uint32_t)wave * (uint32_t)SLAB;
+                    const uint32_t slab_off = (uint32_t)pwave * (uint32_t)SLAB;
                     const uint32_t tap_c = ((uint32_t)qymn & 0xFFFFFFu) * lpitch + ((uint32_t)qxmn << 2) - slab_off;   // uniform
 #pragma unroll
                     for (int j = 0; j < FP_PX; ++j) {
                         weights2(lx[j], ly[j], WS, WO, WC, wx0[j], wx1[j], wy0[j], wy1[j]);
                         const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
-                        const uint32_t* t0 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo);
-                        const uint32_t* t1 = reinterpret_cast<const uint32_t*>(&slab[0][0] + lo + lpitch);
+                        const uint32_t* t0 = reinterpret_cast<const uint32_t*>(slab0 + lo);
+                        const uint32_t* t1 = reinterpret_cast<const uint32_t*>(slab0 + lo + lpitch);
                         a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
                     }
                     const int first = tshift - (lcol + (PW / 2) * h);
@@ -1196,6 +1211,339 @@ __global__ __launch_bounds__(256, 6) void warp_rgb8_comp(const FastArgs a, const
 // one homography per image: image i of the launch uses t.e[i]
 template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fast8_tab(const FastArgs a, const CoefTab t) { fast8_body<DstT, LOG_PW>(a, t.e); }
+
+// ---- several frames per block (round 4): one homography, a batch of frames ---------------------------------------------
+// With one homography for the whole batch (BASELINE configs 2 and 5: n_h == 1) everything a patch computes BEFORE it touches
+// pixel data -- the 8 float64 source coordinates per lane, the footprint, the staging lane map, the 32 tap weights and the 8
+// slab addresses -- is the same in every frame.  The one-frame kernel recomputed it per frame: 186 of its 366 VALU
+// instructions per wave (profiles/r03_isa_histogram.txt: float64 coordinates 69, weights 40, addresses ~45, decode / footprint
+// ~30).  Here a block owns one 128 x 16 tile in mf_frames CONSECUTIVE frames: an interior (staged) wave computes the geometry
+// once, keeps weights and tap addresses in registers (40 VGPRs) and then loops over the frames doing only the data work --
+// stage, 16 tap reads, 32 v_perm + 96 v_fma_mix, pack, store; the next frame's staging loads are in flight while this frame
+// is blended.  Same arithmetic in the same order as fast8_body's staged path (weights as blend4<FOLDED> derives them): the
+// output is bit-identical to the one-frame kernel's (test_warp_multi_frame_equals_single).  Every other kind of wave --
+// border, outside, gather -- is handed to fast8_body frame by frame.
+// 4 blended pixels (U8_BIAS included) -> 12 packed bytes; the same 12 v_cvt_pk_u8_f32 as blend_store's
+__device__ __forceinline__ pk3 pack_run_u8(const float (&o)[FP_PX][3]) {
+    pk3 w;
+    uint32_t q = 0;
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][0], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][1], 1, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][2], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][0], 3, q);
+    w.a = q; q = 0;
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][1], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][2], 1, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][0], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][1], 3, q);
+    w.b = q; q = 0;
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][2], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][0], 1, q);
+    q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][1], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][2], 3, q);
+    w.c = q;
+    return w;
+}
+// ... stored whole, or (the one straddling lane of a ragged row) from local pixel `shift` on, byte by byte
+__device__ __forceinline__ void store_run_pk(const pk3& w, unsigned char* drow, bool store_any, int shift) {
+    if (!store_any) return;
+#ifdef RWH_F8M_STORE_MOD     // lab: cache-policy bits on the multi-frame kernel's stores ("nt", "sc1", "sc0 sc1")
+    if (shift == 0) {
+        typedef uint32_t u3s __attribute__((ext_vector_type(3)));
+        const u3s d = {w.a, w.b, w.c};
+        asm volatile("global_store_dwordx3 %0, %1, off " RWH_F8M_STORE_MOD "\n\ts_nop 2" : : "v"(drow), "v"(d) : "memory");
+        return;
+    }
+#else
+    if (shift == 0) { __builtin_memcpy(drow, &w, 12); return; }
+#endif
+    const unsigned long long lo8 = ((unsigned long long)w.b << 32) | w.a;
+#pragma unroll
+    for (int i = 3; i < 12; ++i)
+        if (i >= 3 * shift) drow[i] = (unsigned char)(i < 8 ? lo8 >> (8 * i) : w.c >> (8 * (i - 8)));
+}
+#ifndef RWH_F8M_SKEW
+#define RWH_F8M_SKEW 8
+#endif
+__device__ __forceinline__ void store_run_u8(const float (&o)[FP_PX][3], unsigned char* drow, bool store_any, int shift) {
+    if (!store_any) return;
+    if (shift == 0) {
+        pk3 w;
+        uint32_t q = 0;
+        q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][0], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][1], 1, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(o[0][2], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][0], 3, q);
+        w.a = q; q = 0;
+        q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][1], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[1][2], 1, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][0], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][1], 3, q);
+        w.b = q; q = 0;
+        q = __builtin_amdgcn_cvt_pk_u8_f32(o[2][2], 0, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][0], 1, q);
+        q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][1], 2, q); q = __builtin_amdgcn_cvt_pk_u8_f32(o[3][2], 3, q);
+        w.c = q;
+        __builtin_memcpy(drow, &w, 12);
+    } else {  // the one straddling lane of a ragged row
+#pragma unroll
+        for (int j = 1; j < FP_PX; ++j)
+            if (j >= shift) {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) drow[3 * j + k] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(o[j][k], 0, 0);
+            }
+    }
+}
+
+// (the four tap weights of every pixel stay in registers across the frames: 32 VGPRs.  Keeping only (wx1, wy1) and re-deriving
+//  the four per frame was tried: hipcc hoists the derivation out of the frame loop again -- same code)
+template <int LOG_PW>
+__device__ __forceinline__ void fast8m_body(const FastArgs& a) {
+    constexpr int PW = 1 << LOG_PW, PH = 512 / PW, LPR = PW / 8, WX = 128 / PW;
+    using Win = F8Window<LOG_PW>;
+    // slab pitch = 2 dwords more than a multiple of 4: the tap reads of a half-wave (four patch rows, lanes 4 texels = 4 dwords
+    // apart) then fall on two bank residues instead of one -- 2-way instead of 4-way conflicts.  With the per-frame arithmetic
+    // halved, the LDS tap reads (16 ds_read2_b32 per wave and frame at 64 cycles each, tools/energy_probe) became the limiter.
+    constexpr uint32_t lpitch = Win::LPITCH + RWH_F8M_SKEW;
+    constexpr int SLAB = ((Win::ROWS * (int)lpitch + 15) / 16) * 16;
+    static_assert(SLAB >= Win::SLAB, "the per-frame fallback body shares this slab");
+    constexpr float WS = W_SCALE * MIX_S, WO = W_ONE * MIX_S, WC = MIX_S;
+    static_assert(MIX_RGB, "the multi-frame kernel is written for the float16-halves blend");
+    unsigned char* const slab0 = wave_slabs<SLAB>();
+
+    // ---- block -> (128 x 16 tile, group of frames); tile fastest, so that neighbouring blocks work on neighbouring tiles of the
+    // same frames.  (Blocks of four patches side by side -- 256 x 8 pixels for 64 x 8 patches -- were tried for DRAM page
+    // locality of the stores: 8K frames 10 % slower, the waves of a 2 x 2 block share their vertical halo in L1 / L2.)
+    const unsigned b = blockIdx.x;
+    const unsigned logical = (b & 7u) * a.mf_cpx + (b >> 3);
+    if (logical >= a.mf_nblocks) return;
+    const unsigned g = a.ntiles_magic ? __umulhi(logical, a.ntiles_magic) : (a.ntiles == 1u ? logical : 0u);
+    const unsigned ti = logical - g * a.ntiles;
+    const int f0 = (int)g * a.mf_frames, f1 = min(f0 + a.mf_frames, a.mf_batch);
+    const unsigned ty = a.tiles_x_magic ? __umulhi(ti, a.tiles_x_magic) : ti;     // ti < ntiles <= nblocks: the magic holds
+    const unsigned tx = ti - ty * a.tiles_x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pwave = wave;
+    {
+        const int own_from = (int)tx * 128 - min((int)tx * 128, a.out_w - 128);
+        if ((wave % WX + 1) * PW <= own_from) return;        // a patch of the moved last tile that owns no column (fast8_body)
+    }
+    const Coef& co = a.c;
+    const int lane = threadIdx.x & 63;
+    const int prow = lane / LPR, pq = lane % LPR;
+    const int wave_x = (wave % WX) * PW, wave_y = (wave / WX) * PH;
+    const int rr_raw = (int)ty * 16 + wave_y + prow;
+    const int rr = min(rr_raw, a.rows - 1);
+    const int tcol0 = (int)tx * 128;
+    const int tcol = min(tcol0, a.out_w - 128);
+    const int tshift = tcol0 - tcol;
+    const int lcol = wave_x + pq * 4;
+    const int c0p = tcol + lcol;
+    const bool store_any = rr_raw < a.rows;
+    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+
+    // ---- the lane's end pixels and the footprint: fast8_body's arithmetic, operation by operation ------------------------
+    const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
+    const double X0 = fma(fc, co.cx[2], fma(fr, co.cx[1], co.cx[0]));
+    const double Y0 = fma(fc, co.cy[2], fma(fr, co.cy[1], co.cy[0]));
+    const double W0 = fma(fc, co.cw[2], fma(fr, co.cw[1], co.cw[0]));
+    uint32_t ehx[2], ehy[2], elx[2], ely[2];
+    bool wpos;
+    {
+        const double X7 = X0 + co.dxs8[6][0], Y7 = Y0 + co.dxs8[6][1], W7 = W0 + co.dxs8[6][2];
+        double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
+        double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
+        const double ux0 = fma(X0, r0, MAGIC), uy0 = fma(Y0, r0, MAGIC), ux7 = fma(X7, r7, MAGIC), uy7 = fma(Y7, r7, MAGIC);
+        ehx[0] = hi32(ux0); elx[0] = lo32(ux0); ehy[0] = hi32(uy0); ely[0] = lo32(uy0);
+        ehx[1] = hi32(ux7); elx[1] = lo32(ux7); ehy[1] = hi32(uy7); ely[1] = lo32(uy7);
+        const int h0 = (int)hi32(W0), h7 = (int)hi32(W7);
+        wpos = __all((int)(h0 > 0x2D300000) & (int)(h0 < 0x52B00000) & (int)(h7 > 0x2D300000) & (int)(h7 < 0x52B00000));
+    }
+    const int x0 = (int)__builtin_amdgcn_readlane(ehx[0], 0), x1 = (int)__builtin_amdgcn_readlane(ehx[1], LPR - 1);
+    const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
+    const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
+    const int hxmn = smin(smin(x0, x1), smin(x2, x3)) & ~3, hxmx = smax(smax(x0, x1), smax(x2, x3));
+    const int hymn = smin(smin(y0, y1), smin(y2, y3)), hymx = smax(smax(y0, y1), smax(y2, y3));
+    const int xmn = (int)((uint32_t)smax(hxmn, 0) - MAGIC_HI), xmx = (int)((uint32_t)smax(hxmx, 0) - MAGIC_HI);
+    const int ymn = (int)((uint32_t)smax(hymn, 0) - MAGIC_HI), ymx = (int)((uint32_t)smax(hymx, 0) - MAGIC_HI);
+    const int nrows = ymx - ymn + 2, C = (xmx - xmn + 5) >> 2;
+    const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
+                        (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
+    if (!staged) {      // outside / border / gather patches: the one-frame body, frame by frame
+        for (int f = f0; f < f1; ++f) fast8_body<unsigned char, LOG_PW, false, 3, false, true>(a, nullptr, nullptr, (int)((unsigned)f * a.ntiles + ti), slab0);
+        return;
+    }
+
+    // ---- staging lane map (fast8_body) ---------------------------------------------------------------------------------
+    unsigned char* my = slab0 + pwave * SLAB;
+    const int srow = lane / Win::LPRW, scol = lane - srow * Win::LPRW;
+    const bool sactive = (srow < Win::RPP) & (scol < C);
+    const uint32_t wl = (uint32_t)srow * lpitch + (uint32_t)scol * 16u;
+    const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)scol));
+    const unsigned char* gsrc = a.src + (long long)f0 * a.src_img_stride + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+    unsigned char* gdst = a.dst + (long long)f0 * a.dst_img_stride;                                                            // uniform
+    const uint32_t doff = ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * 3u;
+    // Staging loads spelled in assembly: scalar row base + per-lane offset (no address VALU), the lane / pass predicate as an
+    // exec mask INSIDE the statement.  Left to hipcc, five conditionally loaded 12-byte tuples that stay live across the blend
+    // all land in ONE register triple and are copied out one by one behind an s_waitcnt vmcnt(0) each: no overlap at all.
+    // The compiler does not count an asm statement's memory operations: `landed` below is the wait.
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    const unsigned long long smask = __ballot(sactive);     // uniform
+    auto issue = [&](const unsigned char* gb, u3 (&v)[Win::PASSES]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < Win::PASSES; ++p) {
+            const int r0 = min(p * Win::RPP, nrows - Win::RPP);
+            const unsigned long long m = p * Win::RPP < nrows ? smask : 0ull;          // uniform
+            const unsigned char* rowbase = gb + (size_t)((uint32_t)r0 * pitch);         // uniform
+            unsigned long long keep;
+#ifdef RWH_ABL_M_NOLOAD      // lab ablation hooks (never defined in the product build)
+            v[p] = u3{goff + (uint32_t)(size_t)rowbase, goff * 3u, goff * 5u}; (void)keep; (void)m;
+#else
+#ifdef RWH_ABL_M_NOREPEAT    // lanes whose row the pass before already staged load nothing
+            const unsigned long long mm = (p > 0 && r0 < p * Win::RPP) ? m & ~((1ull << ((p * Win::RPP - r0) * Win::LPRW)) - 1ull) : m;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\tglobal_load_dwordx3 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                         : "=&v"(v[p]), "=&s"(keep) : "v"(goff), "s"(rowbase), "s"(mm) : "memory");
+#else
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\tglobal_load_dwordx3 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                         : "=&v"(v[p]), "=&s"(keep) : "v"(goff), "s"(rowbase), "s"(m) : "memory");
+#endif
+#endif
+        }
+    };
+    auto landed = [&](u3 (&v)[Win::PASSES]) __attribute__((always_inline)) {
+        // every load issued so far has written its registers (the operands tie the wait to the values)
+        if constexpr (Win::PASSES == 5) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]) : : "memory");
+        else {
+#pragma unroll
+            for (int p = 0; p < Win::PASSES; ++p) asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[p]) : : "memory");
+        }
+    };
+    auto expand = [&](const u3 (&v)[Win::PASSES]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < Win::PASSES; ++p)
+            if (p * Win::RPP < nrows && sactive) {
+                const int r0 = min(p * Win::RPP, nrows - Win::RPP);
+                uint4 t4;
+                t4.x = v[p].x & 0xFFFFFFu;
+                t4.y = __builtin_amdgcn_perm(v[p].y, v[p].x, 0x0C050403u);
+                t4.z = __builtin_amdgcn_perm(v[p].z, v[p].y, 0x0C040302u);
+                t4.w = v[p].z >> 8;
+                // (8-byte aligned when the pitch is skewed: ds_write2_b64)
+                __builtin_memcpy(__builtin_assume_aligned(my + (uint32_t)r0 * lpitch + wl, RWH_F8M_SKEW % 16 ? 8 : 16), &t4, 16);
+            }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // Order at the start of a block: geometry first, then the first frame's chunks.  (Requesting them BEFORE the ~1500 cycles
+    // of coordinate arithmetic -- RWH_F8M_EARLY1, with or without the second frame's right behind, RWH_F8M_EARLY2 -- was 2-4 %
+    // SLOWER on 4K frames and 10 % on 8K frames: what this kernel waits for is the memory system's throughput, and a burst of
+    // requests from every starting block makes that worse, not better.)
+    u3 v[Win::PASSES], v1[Win::PASSES];
+#ifdef RWH_F8M_EARLY1
+    issue(gsrc, v1);
+#ifdef RWH_F8M_EARLY2
+    if (f0 + 1 < f1) issue(gsrc + a.src_img_stride, v);
+#endif
+#endif
+
+    // ---- geometry of the lane's 8 pixels, once: tap weights and slab addresses ---------------------------------------------
+    const uint32_t slab_off = (uint32_t)pwave * (uint32_t)SLAB;
+    const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;   // uniform
+    float wa[F8_PX], wb[F8_PX], wc[F8_PX], wd[F8_PX];      // w00, w01, w10, w11
+    uint32_t lo[F8_PX];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double X[3], Y[3], W[3], rc[3];
+        uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + co.dxs8[3 * h + j][0]; Y[j] = Y0 + co.dxs8[3 * h + j][1]; W[j] = W0 + co.dxs8[3 * h + j][2]; }
+        const double p12 = W[0] * W[1], P = p12 * W[2];
+        double rp = __builtin_amdgcn_rcp(P);                  // staged => wpos: a finite, normal product of positive W
+        rp = fma(fma(-P, rp, 1.0), rp, rp);
+        const double r12 = rp * W[2];
+        rc[2] = rp * p12; rc[0] = r12 * W[1]; rc[1] = r12 * W[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double ux = fma(X[j], rc[j], MAGIC), uy = fma(Y[j], rc[j], MAGIC);
+            const int q = j + 1 - h;
+            hx[q] = hi32(ux); lx[q] = lo32(ux); hy[q] = hi32(uy); ly[q] = lo32(uy);
+        }
+        hx[3 * h] = ehx[h]; lx[3 * h] = elx[h]; hy[3 * h] = ehy[h]; ly[3 * h] = ely[h];
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            const int p = 4 * h + j;
+            const float wx1 = (float)lx[j], wy1 = (float)ly[j] * WS;
+            const float w11 = wx1 * wy1;                     // blend4<FOLDED>'s derivation
+            const float w01 = __builtin_fmaf(wx1, WO, -w11);
+            const float w10 = __builtin_fmaf(wy1, 4294967296.0f, -w11);
+            const float w00 = __builtin_fmaf(-wx1, WO, WC) - w10;
+            wa[p] = w00; wb[p] = w01; wc[p] = w10; wd[p] = w11;
+            lo[p] = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
+        }
+    }
+
+#ifdef RWH_F8M_EARLY1
+    // (volatile statements keep their order: these pin the arithmetic above IN FRONT of the wait below -- left alone, hipcc
+    //  sinks it behind the s_waitcnt, where it overlaps nothing)
+#pragma unroll
+    for (int p = 0; p < F8_PX; ++p) asm volatile("" : : "v"(wa[p]), "v"(wb[p]), "v"(wc[p]), "v"(wd[p]), "v"(lo[p]));
+#else
+    issue(gsrc, v1);
+#endif
+    landed(v1);
+    expand(v1);
+#ifndef RWH_F8M_EARLY2
+    if (f0 + 1 < f1) issue(gsrc + a.src_img_stride, v);
+#endif
+#ifdef RWH_LAB_STAMPS       // lab build only: cycles per phase, summed over the frames, written over the first bytes of the output
+    unsigned long long tA = 0, tB = 0, tC = 0, tD = 0, t0 = __builtin_amdgcn_s_memtime(), t1;
+#define RWH_STAMP(acc) { t1 = __builtin_amdgcn_s_memtime(); acc += t1 - t0; t0 = t1; }
+#else
+#define RWH_STAMP(acc)
+#endif
+    for (int f = f0; f < f1; ++f) {
+        gsrc += a.src_img_stride;
+        const bool more = f + 1 < f1;                         // uniform
+        pk3 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float o[FP_PX][3];
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const int p = 4 * h + j;
+                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(slab0 + lo[p]);
+                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(slab0 + lo[p] + lpitch);
+                const uint32_t a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
+                const float w00 = wa[p], w01 = wb[p], w10 = wc[p], w11 = wd[p];
+                const uint32_t g00 = rg_halves(a0), g01 = rg_halves(b0), g10 = rg_halves(a1), g11 = rg_halves(b1);
+                o[j][0] = fmix_lo(g11, w11, fmix_lo(g10, w10, fmix_lo(g01, w01, fmix_lo_c(g00, w00, U8_BIAS))));
+                o[j][1] = fmix_hi(g11, w11, fmix_hi(g10, w10, fmix_hi(g01, w01, fmix_hi_c(g00, w00, U8_BIAS))));
+                o[j][2] = fmix_hi(b1, w11, fmix_hi(a1, w10, fmix_hi(b0, w01, fmix_hi_c(a0, w00, U8_BIAS))));
+            }
+            w[h] = pack_run_u8(o);
+        }
+        // this frame's tap reads are complete (their values were consumed above; LDS is in order): the slab is free
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        RWH_STAMP(tA)
+        if (more) { landed(v); RWH_STAMP(tB) expand(v); }
+        RWH_STAMP(tC)
+        unsigned char* drow = gdst + doff;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int first = tshift - (lcol + (PW / 2) * h);
+#ifdef RWH_ABL_M_NOSTORE
+            if (w[h].a + w[h].b == 0x12345u)
+#endif
+            store_run_pk(w[h], drow + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
+        }
+        gdst += a.dst_img_stride;
+        if (f + 2 < f1) issue(gsrc + a.src_img_stride, v);    // two frames ahead: in flight during the whole next blend
+        RWH_STAMP(tD)
+    }
+#ifdef RWH_LAB_STAMPS
+    if (lane == 0 && logical < 8192u) {
+        unsigned long long* st = reinterpret_cast<unsigned long long*>(a.dst) + ((size_t)logical * 4 + pwave) * 4;
+        st[0] = tA; st[1] = tB; st[2] = tC; st[3] = tD;
+    }
+#endif
+}
+#ifndef RWH_F8M_WAVES
+#define RWH_F8M_WAVES 4
+#endif
+template <int LOG_PW>
+__global__ __launch_bounds__(256, RWH_F8M_WAVES) void warp_rgb8_fast8m(const FastArgs a) { fast8m_body<LOG_PW>(a); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.

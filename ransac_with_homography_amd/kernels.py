@@ -438,3 +438,32 @@ class ClockProbe:
         self.stream.synchronize()
         cyc, ticks = (int(v) for v in self.out.cpu())
         return 100.0 * cyc / ticks if ticks else float("nan")
+
+
+def power_node(device_index=None):
+    """Path of the amdgpu hwmon file holding this device's board power in microwatts (power1_average / power1_input), or
+    None.  Read it with open(): a process that has initialised the GPU must not fork + exec a tool like rocm-smi."""
+    import glob
+    try:
+        idx = torch.cuda.current_device() if device_index is None else int(device_index)
+        bus = torch.cuda.get_device_properties(idx).pci_bus_id
+        dom = getattr(torch.cuda.get_device_properties(idx), "pci_domain_id", 0)
+        dev = getattr(torch.cuda.get_device_properties(idx), "pci_device_id", 0)
+        pci = "%04x:%02x:%02x.0" % (dom, bus, dev)
+    except Exception:
+        return None
+    for leaf in ("power1_average", "power1_input"):
+        hits = glob.glob("/sys/bus/pci/devices/%s/hwmon/hwmon*/%s" % (pci, leaf))
+        if hits:
+            return hits[0]
+    return None
+
+
+def power_cap_node(device_index=None):
+    """The same device's power cap (microwatts), or None."""
+    node = power_node(device_index)
+    if not node:
+        return None
+    import os
+    cap = os.path.join(os.path.dirname(node), "power1_cap")
+    return cap if os.path.exists(cap) else None

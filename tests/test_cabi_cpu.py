@@ -115,7 +115,12 @@ def test_new_entry_points_validate_and_plan(lib):
     inv = np.linalg.inv(Hs)
     g = kernels.Grid(5, 3775, 3771, 7, 2034, 2028)
     plan = lambda shape, dt, *a, **k: kernels.warp_plan(shape, dt, inv, g, (2160, 3840), *a, **k)
+    # a batch with one homography: the lab knob RWH_TUNE_WARP_FRAMES selects the multi-frame kernel (round 4; off by default)
     assert plan((32, 2160, 3840, 3), torch.uint8, "bilinear", torch.uint8) == "rwh::warp_rgb8_fast8<unsigned char, 6>"
+    assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_FRAMES, 65) == -1 and lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_FRAMES, 4) == 0
+    assert plan((32, 2160, 3840, 3), torch.uint8, "bilinear", torch.uint8) == "rwh::warp_rgb8_fast8m<6>"
+    assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_FRAMES, 0) == 0
+    assert plan((2160, 3840, 3), torch.uint8, "bilinear", torch.uint8) == "rwh::warp_rgb8_fast8<unsigned char, 6>"
     assert plan((2160, 3840, 3), torch.uint8, "bilinear", torch.float32) == "rwh::warp_rgb8_fast8<float, 6>"
     assert plan((2160, 3840, 3), torch.uint8, "nn", torch.uint8) == "rwh::warp_rgb8_nn<6>"
     assert plan((2160, 3840, 3), torch.uint8, "bilinear", torch.float64, exact=True) == "rwh::warp_exact<unsigned char, 3, double, 1>"

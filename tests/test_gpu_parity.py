@@ -48,10 +48,17 @@ def _force_shape(shape):
     assert _lib.load().rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, int(shape) if shape else 0) == 0
 
 
+def _force_frames(n):
+    """Frames per block of the multi-frame lab kernel (warp_rgb8_fast8m; 0 = the product's one-frame kernel)."""
+    from ransac_with_homography_amd import _lib
+    assert _lib.load().rwh_lab_tune(_lib.RWH_TUNE_WARP_FRAMES, int(n)) == 0
+
+
 @pytest.fixture(autouse=True)
 def release_lab_overrides():
     yield
     _force_shape(None)
+    _force_frames(0)
 
 
 def close(gpu_img, ref):
@@ -1230,6 +1237,44 @@ def test_warp_patch_shapes_vs_oracle(gpu, case, shape, monkeypatch):
     # row shards of the same launch reproduce it bit for bit (tile rows restart at the shard's first row)
     part = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8, rows=(100, 229)).cpu().numpy()
     assert np.array_equal(part, u8[100:229])
+
+
+@pytest.mark.parametrize("shape", ["7", "6", "5"])
+@pytest.mark.parametrize("case", ["mild", "rot4", "persp"])
+def test_warp_multi_frame_equals_single(gpu, case, shape):
+    """The multi-frame lab kernel (rwh_lab_tune RWH_TUNE_WARP_FRAMES, warp_rgb8_fast8m: a block walks its tile through n
+    consecutive frames of a one-homography batch, the patch's coordinate / weight arithmetic done once) against the product's
+    one-frame kernel: BIT-IDENTICAL, every patch shape, frames per block that do and do not divide the batch, on a grid with
+    ragged right / bottom tiles, border patches and patches wholly outside the source, whole launches and row shards."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(21)
+    imgs = rng.integers(0, 256, (7, 333, 517, 3), dtype=np.uint8)
+
+    def rot(deg, sc=1.0):
+        t = np.deg2rad(deg)
+        c, s, cx, cy = sc * np.cos(t), sc * np.sin(t), 258.0, 166.0
+        return np.array([[c, -s, cx - c * cx + s * cy], [s, c, cy - s * cx - c * cy], [0, 0, 1.0]])
+    H = {"mild": np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]]), "rot4": rot(4),
+         "persp": np.array([[0.9, 0.2, 11.0], [-0.15, 1.1, 30.0], [3e-4, -2e-4, 1.0]])}[case]
+    inv = np.linalg.inv(H)
+    grid = kernels.Grid(-40, 609, 650, -25, 385, 411)      # overhangs the source on every side; 650 = 5 tiles + 10 columns
+    src = torch.from_numpy(imgs).to(gpu)
+    _force_shape(shape)
+    _force_frames(0)
+    ref = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8)
+    assert "fast8<" in kernels.warp_plan(tuple(src.shape), torch.uint8, inv, grid, (333, 517), "bilinear", torch.uint8)
+    for n in (2, 3, 4, 7, 16):
+        _force_frames(n)
+        assert "fast8m" in kernels.warp_plan(tuple(src.shape), torch.uint8, inv, grid, (333, 517), "bilinear", torch.uint8)
+        got = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8)
+        assert torch.equal(got, ref), (case, shape, n, int((got != ref).sum()))
+        part = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8, rows=(100, 229))
+        assert torch.equal(part, ref[:, 100:229]), (case, shape, n)
+    # and the one-frame kernel's own check against the oracle holds for what both produce
+    xs, ys = np.linspace(-40, 609, 650), np.linspace(-25, 385, 411)
+    o = _oracle_warp_on_grid(imgs[3], inv, xs, ys, (333, 517))
+    d = np.abs(ref[3].cpu().numpy().astype(np.int16) - o.astype(np.uint8).astype(np.int16))
+    assert (d > 1).sum() <= 9, (case, shape, int((d > 1).sum()))
 
 
 @pytest.mark.parametrize("case", ["zoom1p4", "zoom1p6", "zoom2", "zoom2_rot3", "persp_zoom", "zoom3"])

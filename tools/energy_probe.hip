@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <cctype>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
 constexpr int ITERS = 2048;
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -95,6 +96,35 @@ __global__ __launch_bounds__(256) void k_pk_mul(ARGS) {
     f2 s = a0+a1+a2+a3+a4+a5+a6+a7;
     if (seed == 77777u) out[threadIdx.x] = s.x + s.y;
 }
+
+
+// ---- scalar unit (round 4): 64 scalar instructions per loop iteration (the loop's own s_add / s_cmp / s_cbranch are 3 more) ----
+#define S8(X) X X X X X X X X
+#define S64(X) S8(X) S8(X) S8(X) S8(X) S8(X) S8(X) S8(X) S8(X)
+#define SK(NAME, BODY, CLOB) \
+__global__ __launch_bounds__(256) void NAME(ARGS) { unsigned s0 = seed | 1u, s1 = seed * 3u + 7u, s2 = 0u; STAMP0 \
+    for (int it = 0; it < ITERS / 4; ++it) { asm volatile(S64(BODY) : "+s"(s0), "+s"(s1), "+s"(s2) : : CLOB); } \
+    STAMP1 if (seed == 77777u) out[threadIdx.x] = (float)(s0 + s1 + s2); }
+SK(k_s_add, "s_add_i32 %0, %0, %1\n", "scc")
+SK(k_s_mul, "s_mul_i32 %0, %0, %1\n", "scc")
+SK(k_s_min, "s_min_i32 %2, %0, %1\n", "scc")
+SK(k_s_and64, "s_and_b64 vcc, vcc, exec\n", "vcc" COMMA "scc")
+SK(k_s_csel, "s_cmp_lt_i32 %0, %1\n s_cselect_b32 %2, %0, %1\n", "scc")
+SK(k_s_mov, "s_mov_b32 %2, %0\n", "scc")
+SK(k_s_nop, "s_nop 0\n", "scc")
+SK(k_s_waitcnt, "s_waitcnt lgkmcnt(0)\n", "scc")
+SK(k_s_saveexec, "s_and_saveexec_b64 vcc, exec\n s_mov_b64 exec, vcc\n", "vcc" COMMA "scc")
+SK(k_s_branch, "s_cmp_eq_u32 %0, 0\n s_cbranch_scc1 1f\n1:\n", "scc")
+__global__ __launch_bounds__(256) void k_v_readlane(ARGS) { unsigned v = RND(0), s0 = 0; STAMP0
+    for (int it = 0; it < ITERS / 4; ++it) { asm volatile(S64("v_readlane_b32 %0, %1, 5\n") : "+s"(s0) : "v"(v)); }
+    STAMP1 if (seed == 77777u) out[threadIdx.x] = (float)s0; }
+__global__ __launch_bounds__(256) void k_v_cmp(ARGS) { unsigned v = RND(0), w = RND(1); STAMP0
+    for (int it = 0; it < ITERS / 4; ++it) { asm volatile(S64("v_cmp_lt_u32 vcc, %0, %1\n") : : "v"(v), "v"(w) : "vcc"); }
+    STAMP1 if (seed == 77777u) out[threadIdx.x] = (float)v; }
+// scalar loads that hit the scalar cache (the kernel-argument segment): 16 bytes each
+__global__ __launch_bounds__(256) void k_s_load(ARGS) { u4 q; unsigned acc = 0; const unsigned* p = gsrc + (blockIdx.x & 15) * 64; STAMP0
+    for (int it = 0; it < ITERS / 4; ++it) { asm volatile(S8("s_load_dwordx4 %0, %1, 0x0\n s_load_dwordx4 %0, %1, 0x10\n s_load_dwordx4 %0, %1, 0x20\n s_load_dwordx4 %0, %1, 0x30\n s_load_dwordx4 %0, %1, 0x40\n s_load_dwordx4 %0, %1, 0x50\n s_load_dwordx4 %0, %1, 0x60\n s_load_dwordx4 %0, %1, 0x70\n") "s_waitcnt lgkmcnt(0)\n" : "=&s"(q) : "s"(p) : "memory"); acc += q.x; }
+    STAMP1 if (seed == 77777u) out[threadIdx.x] = (float)acc; }
 
 // ---- LDS -------------------------------------------------------------------------------------------------------------
 // stride in dwords between neighbouring lanes: 1 = conflict-free b32, 4 = the warp kernel's tap pattern (16 B apart)
@@ -190,16 +220,29 @@ __global__ void k_check(float* out) {
 
 struct Case { const char* name; void (*k)(ARGS); double inst_per_wave; double bytes; };
 static std::atomic<bool> g_stop{false};
+static std::string g_power_path;
+// the board power from the amdgpu hwmon node of THIS device (microwatts); no child process: a program that has initialised the GPU must not exec
+static void find_power_node() {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, 0) != hipSuccess) return;
+    for (char* p = bus; *p; ++p) *p = (char)tolower(*p);
+    for (int h = 0; h < 64; ++h)
+        for (const char* leaf : {"power1_average", "power1_input"}) {
+            char path[256]; snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/hwmon/hwmon%d/%s", bus, h, leaf);
+            FILE* f = fopen(path, "r"); if (f) { fclose(f); g_power_path = path; return; }
+        }
+}
 static void sampler(std::vector<double>* watts) {
     while (!g_stop) {
-        FILE* f = popen("rocm-smi --showpower 2>/dev/null | grep -i 'Power (W)'", "r");
-        if (f) { char buf[512]; if (fgets(buf, sizeof buf, f)) { const char* p = strrchr(buf, ':'); if (p) watts->push_back(atof(p + 1)); } pclose(f); }
-        std::this_thread::sleep_for(std::chrono::milliseconds(100));
+        FILE* f = g_power_path.empty() ? nullptr : fopen(g_power_path.c_str(), "r");
+        if (f) { double uw = 0; if (fscanf(f, "%lf", &uw) == 1) watts->push_back(uw * 1e-6); fclose(f); }
+        std::this_thread::sleep_for(std::chrono::milliseconds(50));
     }
 }
 
 int main(int argc, char** argv) {
     const char* filter = argc > 1 ? argv[1] : "";
+    find_power_node(); printf("power node: %s\n", g_power_path.empty() ? "(none)" : g_power_path.c_str());
     unsigned long long* stamps; float* out; unsigned *src, *dst;
     CK(hipMalloc(&stamps, 2048 * 16)); CK(hipMalloc(&out, 4096));
     CK(hipMalloc(&src, (size_t)1 << 30)); CK(hipMalloc(&dst, (size_t)1 << 30));
@@ -224,6 +267,10 @@ int main(int argc, char** argv) {
         {"ds_read_b64 s2", k_lds<2, 2>, I8, 0}, {"ds_read_b64 s8", k_lds<8, 2>, I8, 0}, {"ds_read_b128 s4", k_lds<4, 3>, I8, 0},
         {"ds_write_b32 s1", k_lds<1, 4>, I8, 0}, {"ds_write_b128 s4", k_lds<4, 5>, I8, 0},
         {"gload L2 dword", k_gload_l2<4>, 2.0 * ITERS, 0}, {"gload L2 dwordx3", k_gload_l2<12>, 2.0 * ITERS, 0}, {"gload L2 dwordx4", k_gload_l2<16>, 2.0 * ITERS, 0},
+        {"s_add_i32", k_s_add, 16.0 * ITERS, 0}, {"s_mul_i32", k_s_mul, 16.0 * ITERS, 0}, {"s_min_i32", k_s_min, 16.0 * ITERS, 0}, {"s_and_b64", k_s_and64, 16.0 * ITERS, 0},
+        {"s_cmp+s_cselect (2)", k_s_csel, 32.0 * ITERS, 0}, {"s_mov_b32", k_s_mov, 16.0 * ITERS, 0}, {"s_nop 0", k_s_nop, 16.0 * ITERS, 0}, {"s_waitcnt", k_s_waitcnt, 16.0 * ITERS, 0},
+        {"saveexec+mov exec (2)", k_s_saveexec, 32.0 * ITERS, 0}, {"s_cmp+s_cbranch (2)", k_s_branch, 32.0 * ITERS, 0}, {"v_readlane_b32", k_v_readlane, 16.0 * ITERS, 0},
+        {"v_cmp_lt_u32", k_v_cmp, 16.0 * ITERS, 0}, {"s_load_dwordx4 hit", k_s_load, 16.0 * ITERS, 0},
         {"stream read 16B", k_stream_read, 0, 4.0 * (double)((size_t)1 << 30)}, {"stream write 16B", k_stream_write, 0, 4.0 * (double)((size_t)1 << 30)},
     };
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));

@@ -39,8 +39,10 @@ inv = np.linalg.inv(H_S)
 out = torch.empty((frames, oh, ow, 3), dtype=torch.uint8, device=dev)
 lib = _lib.load()
 ref = None
-for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
+# MF=<a,b,..>: frames per block of the multi-frame kernel (rwh_lab_tune RWH_TUNE_WARP_FRAMES: 0 = the library's choice, 1 = the one-frame kernel)
+for kind, mf in [(int(a), int(m)) for a in (sys.argv[1:] or ["0", "5", "6", "7"]) for m in os.environ.get("MF", "0").split(",")]:
     assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_SHAPE, kind) == 0
+    assert lib.rwh_lab_tune(_lib.RWH_TUNE_WARP_FRAMES, mf) == 0
     for _ in range(60): kernels.warp_backward(src, inv, grid, (Hh, W), "bilinear", torch.uint8, zero_origin=False, out=out)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -58,13 +60,14 @@ for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
     plan = kernels.warp_plan((frames, Hh, W, 3), torch.uint8, inv, grid, (Hh, W), "bilinear", torch.uint8)
     watts = ""
     if os.environ.get("POWER"):          # POWER=1: 3 more seconds of back-to-back launches with rocm-smi sampled meanwhile
-        import subprocess, threading, time, re
+        import threading, time, glob
         samples, stop = [], threading.Event()
+        node = kernels.power_node()           # amdgpu hwmon file of this device (no child process: this program holds the GPU)
         def sampler():
-            while not stop.is_set():
-                o = subprocess.run("rocm-smi --showpower", shell=True, capture_output=True, text=True).stdout
-                m = re.search(r"Power \(W\): ([0-9.]+)", o)
-                if m: samples.append(float(m.group(1)))
+            while not stop.is_set() and node:
+                try: samples.append(int(open(node).read()) * 1e-6)
+                except (OSError, ValueError): pass
+                time.sleep(0.02)
         th = threading.Thread(target=sampler); th.start()
         t_end = time.time() + 3.0
         p2 = kernels.ClockProbe(1500.0)
@@ -75,4 +78,4 @@ for kind in [int(a) for a in sys.argv[1:]] or [0, 5, 6, 7]:
         tail = sorted(samples[len(samples) // 2:])
         watts = "  power %.0f W (median of %d samples, max %.0f) sclk(1.5 s) %.0f MHz" % (tail[len(tail) // 2] if tail else 0, len(tail), max(samples or [0]), p2.mhz())
     print(plan, end="  ")
-    print("kind %2d  %.4f ms per %d frames = %.2f us/frame  %.0f GB/s = %.3f of 8 TB/s  sclk %.0f MHz%s" % (kind, ms, frames, ms * 1e3 / frames, by / ms / 1e6, by / ms / 1e6 / 8000, probe.mhz(), same) + watts + (" sha1 " + digest if digest else ""), flush=True)
+    print("kind %2d mf %3d  %.4f ms per %d frames = %.2f us/frame  %.0f GB/s = %.3f of 8 TB/s  sclk %.0f MHz%s" % (kind, mf, ms, frames, ms * 1e3 / frames, by / ms / 1e6, by / ms / 1e6 / 8000, probe.mhz(), same) + watts + (" sha1 " + digest if digest else ""), flush=True)
