@@ -314,6 +314,15 @@ RWH_API int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, con
 RWH_API int rwh_host_inv3(const float* h, int n, void* dgesv_ilp64, float* out);
 
 /*
+ * Host code: `count` draws of numpy's LEGACY np.random.randint(0, m, ...) (ransac.py:177 samples with it) from the MT19937 state
+ * the caller took with RandomState.get_state() -- key[624], pos, updated in place for set_state() --: the identical stream
+ * (one 32-bit output per draw, masked, rejected above m - 1; m == 1 draws nothing), without the interpreter and the generator's
+ * lock around every draw.  out32 (int32, the index table the kernels take) and / or out64 (what numpy returns) may be NULL.
+ * 1 <= m < 2^31.  tests/test_settle_cpu.py holds it to numpy's own output.
+ */
+RWH_API int rwh_host_legacy_randint(uint32_t* key, int32_t* pos, int64_t m, int64_t count, int32_t* out32, int64_t* out64);
+
+/*
  * The host driver of RANSAC.run (ransac.py:159-213 up to, not including, the final refit) as ONE native call: upload,
  * rwh_ransac_search, the settle step -- the reference's own solver (rwh_host_dlt4_svd) for every sample K1 flags and every
  * hypothesis whose count is within min(margin_cap, 3 + count / 16) of a decision (the best count, `need`), re-scored by

@@ -25,7 +25,8 @@ RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT, RWH_TUNE_WARP_FRA
 # every symbol include/rwh.h declares (tests check the library exports them all)
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama",
-           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check", "rwh_score_count_inv", "rwh_host_inv3", "rwh_stitch_panorama_rows")
+           "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check", "rwh_score_count_inv", "rwh_host_inv3", "rwh_stitch_panorama_rows",
+           "rwh_host_legacy_randint")
 
 
 class RwhUnavailable(RuntimeError):
@@ -87,6 +88,8 @@ def _bind(lib):
     lib.rwh_project_points.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.rwh_host_dlt4_svd.restype = i32
     lib.rwh_host_dlt4_svd.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
+    lib.rwh_host_legacy_randint.restype = i32
+    lib.rwh_host_legacy_randint.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.rwh_ransac_run_layout.restype = i32
     lib.rwh_ransac_run_layout.argtypes = [i32, i32, vp, i32]
     lib.rwh_ransac_run.restype = i32

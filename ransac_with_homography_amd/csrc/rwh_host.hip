@@ -167,3 +167,78 @@ extern "C" int rwh_host_inv3(const float* h, int n, void* dgesv_ilp64, float* ou
     }
     return RWH_OK;
 }
+
+
+// ---- the sample table of RANSAC.run, drawn exactly as numpy's legacy generator draws it (ransac.py:177) ---------------------
+// k successive np.random.randint(0, m, n) calls consume the global RandomState (MT19937) like ONE randint(0, m, (k, n)) call does
+// (SURVEY A.4).  For a range below 2^32 numpy's legacy randint takes one 32-bit output per draw, masks it with the smallest
+// 2^b - 1 >= m - 1 and rejects values above m - 1 (numpy/random/src/distributions: random_bounded_uint64_fill with
+// use_masked -> buffered_bounded_masked_uint32); m == 1 consumes nothing.  numpy's own loop costs ~5 ns per draw behind the
+// interpreter and the generator's lock -- 2.1 ms of a 5.3 ms RANSAC.run at k = 100 000 --; this one is the same arithmetic in
+// a tight loop.  `key` / `pos`: RandomState.get_state()[1:3], updated in place for set_state().  out32 (k x n, the kernel's
+// index table) and / or out64 (the int64 array numpy would have returned) may be NULL.
+namespace {
+inline void mt19937_refill(uint32_t* mt) {
+    constexpr int N = 624, M = 397;
+    constexpr uint32_t UPPER = 0x80000000u, LOWER = 0x7fffffffu, A = 0x9908b0dfu;
+    int kk = 0;
+    for (; kk < N - M; ++kk) { const uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER); mt[kk] = mt[kk + M] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+    for (; kk < N - 1; ++kk) { const uint32_t y = (mt[kk] & UPPER) | (mt[kk + 1] & LOWER); mt[kk] = mt[kk + (M - N)] ^ (y >> 1) ^ ((y & 1u) ? A : 0u); }
+    const uint32_t y = (mt[N - 1] & UPPER) | (mt[0] & LOWER);
+    mt[N - 1] = mt[M - 1] ^ (y >> 1) ^ ((y & 1u) ? A : 0u);
+}
+}  // namespace
+
+extern "C" int rwh_host_legacy_randint(uint32_t* key, int32_t* pos, int64_t m, int64_t count, int32_t* out32, int64_t* out64) {
+    if (!key || !pos || m <= 0 || m > 0x7fffffffll || count < 0 || *pos < 0 || *pos > 624) return RWH_E_INVALID;
+    const uint32_t rng = (uint32_t)(m - 1);
+    if (rng == 0) {                                   // numpy: "rng == 0: out = off", no draw
+        for (int64_t i = 0; i < count; ++i) { if (out32) out32[i] = 0; if (out64) out64[i] = 0; }
+        return RWH_OK;
+    }
+    uint32_t mask = rng;
+    mask |= mask >> 1; mask |= mask >> 2; mask |= mask >> 4; mask |= mask >> 8; mask |= mask >> 16;
+    int p = *pos;
+    int64_t i = 0;
+    // whole blocks of the state while they cannot over-run the table (every raw output yields at most one draw): tempering and
+    // a branch-free compaction -- the rejection branch (28 % taken at m = 185) is what makes the obvious loop 7 ns per draw
+    while (count - i >= 624) {
+        if (p == 624) { mt19937_refill(key); p = 0; }
+        uint32_t t[624];
+        const int nraw = 624 - p;
+        for (int q = 0; q < nraw; ++q) {
+            uint32_t y = key[p + q];
+            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+            t[q] = y & mask;
+        }
+        p = 624;
+        if (out32 && out64) {
+            int64_t j = i;
+            for (int q = 0; q < nraw; ++q) { out32[j] = (int32_t)t[q]; out64[j] = (int64_t)t[q]; j += (t[q] <= rng); }
+            i = j;
+        } else if (out32) {
+            int64_t j = i;
+            for (int q = 0; q < nraw; ++q) { out32[j] = (int32_t)t[q]; j += (t[q] <= rng); }
+            i = j;
+        } else if (out64) {
+            int64_t j = i;
+            for (int q = 0; q < nraw; ++q) { out64[j] = (int64_t)t[q]; j += (t[q] <= rng); }
+            i = j;
+        } else {
+            for (int q = 0; q < nraw; ++q) i += (t[q] <= rng);
+        }
+    }
+    for (; i < count; ++i) {                              // the tail, draw by draw
+        uint32_t v;
+        do {
+            if (p == 624) { mt19937_refill(key); p = 0; }
+            uint32_t y = key[p++];
+            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+            v = y & mask;
+        } while (v > rng);
+        if (out32) out32[i] = (int32_t)v;
+        if (out64) out64[i] = (int64_t)v;
+    }
+    *pos = p;
+    return RWH_OK;
+}

@@ -191,3 +191,35 @@ def test_illcond_flag_and_settle_on_lattice_problems(oracle_scorer):
             inl = np.flatnonzero(np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:A.shape[0]])
         assert np.array_equal(inl, z[key + "_inliers"]), key
         assert stats["host_rounds"] <= 2, (key, stats)
+
+
+def test_native_legacy_randint_is_numpys_stream():
+    """rwh_host_legacy_randint (the index table of RANSAC.run, ransac.py:177) against numpy's own legacy randint: the same
+    values, the same dtype for the int64 form, and the global generator left in the same place -- for ranges on and around
+    powers of two (the rejection mask changes there), m = 1 (no draw), the largest range, arbitrary starting positions
+    inside the MT19937 block, and table sizes that end inside / exactly on a block of 624 outputs."""
+    rng = np.random.default_rng(1)
+    ms = [1, 2, 3, 4, 5, 127, 128, 129, 185, 255, 256, 257, 1000, 65535, 65536, 65537, 2 ** 31 - 1]
+    for case in range(120):
+        m = int(ms[case % len(ms)]) if case < 60 else int(rng.integers(1, 10 ** 6))
+        k, n = int(rng.integers(1024, 3000)), int(rng.choice([4, 4, 6, 1]))
+        np.random.seed(int(rng.integers(0, 2 ** 31)))
+        np.random.randint(0, 1000, int(rng.integers(0, 700)))
+        st = np.random.get_state()
+        a64, a32 = impl.legacy_randint_table(m, k, n)
+        nxt_a = np.random.randint(0, 2 ** 30, 3)
+        np.random.set_state(st)
+        b = np.random.randint(0, m, (k, n))
+        nxt_b = np.random.randint(0, 2 ** 30, 3)
+        assert a64.dtype == b.dtype and np.array_equal(a64, b) and a32.dtype == np.int32 and np.array_equal(a32, b), (m, k, n)
+        assert np.array_equal(nxt_a, nxt_b), (m, k, n)
+    # a small table (numpy's own call is used) and the int32-only form
+    np.random.seed(5); st = np.random.get_state()
+    a64, a32 = impl.legacy_randint_table(185, 10, 4)
+    np.random.set_state(st)
+    assert np.array_equal(a64, np.random.randint(0, 185, (10, 4)))
+    np.random.seed(6); st = np.random.get_state()
+    none64, a32 = impl.legacy_randint_table(185, 5000, 4, want64=False)
+    nxt = np.random.randint(0, 99)
+    np.random.set_state(st)
+    assert none64 is None and np.array_equal(a32, np.random.randint(0, 185, (5000, 4))) and nxt == np.random.randint(0, 99)
