@@ -22,7 +22,8 @@
 extern "C" {
 #endif
 
-#define RWH_ABI_VERSION 2   /* 2: blend modes of rwh_stitch_panorama, RWH_BATCH_EARLY_STOP (d_counts may hold -1), rwh_lab_clock_probe, RWH_HYP_ILLCOND */
+#define RWH_ABI_VERSION 3   /* 3 (round 4): rwh_ransac_run takes hyp_base and returns packed keys, RWH_HYP_DEGENERATE, rwh_score_interval;
+                               2: blend modes of rwh_stitch_panorama, RWH_BATCH_EARLY_STOP (d_counts may hold -1), rwh_lab_clock_probe, RWH_HYP_ILLCOND */
 #define RWH_API __attribute__((visibility("default")))
 
 enum {
@@ -185,6 +186,10 @@ RWH_API int rwh_warp_plan(int src_h, int src_w, int channels, int src_dtype, int
                                 In searches that invert the hypotheses (rwh_ransac_search / _batched with 'backward' or 'reproj')
                                 the bit is also set for a nearly singular H (|det| below 1e-6 of the sum of the six products'
                                 magnitudes): its inverse must be numpy.linalg.inv's own (rwh_score_count_inv). */
+#define RWH_HYP_DEGENERATE 8u /* bit 3 (round 4; implies bit 2): the ill-conditioned samples whose H says nothing about the
+                                reference's -- a pivot below 1e-7 of its column's scale, |n[8]| < 1e-7, a nearly singular H in a
+                                search that inverts.  Always host-solved.  The other RWH_HYP_ILLCOND samples are accurate
+                                here and, under 'fwd', are bounded by rwh_score_interval instead. */
 RWH_API int rwh_dlt4_batched(const float* d_pts_a, const float* d_pts_b, int m,
                      const int32_t* d_idx, int k,
                      float* d_h, uint8_t* d_flags, void* stream);
@@ -314,6 +319,20 @@ RWH_API int rwh_host_dlt4_svd(const float* pts_a, const float* pts_b, int m, con
 RWH_API int rwh_host_inv3(const float* h, int n, void* dgesv_ilp64, float* out);
 
 /*
+ * The inlier count of listed hypotheses as an interval ('fwd' loss, ransac.py:55-64 + 78-82 + 183): for row d_rows[i] of d_h
+ * (d_rows NULL: rows 0 .. n_rows-1), d_lo[i] = the pairs that are inliers for EVERY H within the perturbation budget of d_h's row,
+ * d_hi[i] = the pairs that are inliers for SOME such H.  Budget: every entry may move by delta x its natural scale (rows 0 / 1:
+ * s, s, s C; row 2: s / C, s / C, s with C = coord_scale >= 1, the magnitude of the coordinates, and s the largest scale-free
+ * entry), delta = delta1 for rows whose d_flags byte has RWH_HYP_ILLCOND set, delta0 otherwise (d_flags may be NULL).  The settle
+ * step of RANSAC.run uses it to decide which hypotheses need the reference's own solver: LAPACK's float32 H lies within a few
+ * ulps (natural scale) of K1's, so d_lo == d_hi means the reference's count IS rwh_score_count's, and a d_hi below the best
+ * d_lo cannot win.  th as in rwh_score_count.
+ */
+RWH_API int rwh_score_interval(const float* d_h, const int32_t* d_rows, int n_rows, const uint8_t* d_flags, const float* d_pts_a,
+                       const float* d_pts_b, int m, double th, double coord_scale, double delta0, double delta1,
+                       int32_t* d_lo, int32_t* d_hi, void* stream);
+
+/*
  * Host code: `count` draws of numpy's LEGACY np.random.randint(0, m, ...) (ransac.py:177 samples with it) from the MT19937 state
  * the caller took with RandomState.get_state() -- key[624], pos, updated in place for set_state() --: the identical stream
  * (one 32-bit output per draw, masked, rejected above m - 1; m == 1 draws nothing), without the interpreter and the generator's
@@ -324,27 +343,37 @@ RWH_API int rwh_host_legacy_randint(uint32_t* key, int32_t* pos, int64_t m, int6
 
 /*
  * The host driver of RANSAC.run (ransac.py:159-213 up to, not including, the final refit) as ONE native call: upload,
- * rwh_ransac_search, the settle step -- the reference's own solver (rwh_host_dlt4_svd) for every sample K1 flags and every
- * hypothesis whose count is within min(margin_cap, 3 + count / 16) of a decision (the best count, `need`), re-scored by
- * rwh_score_count; the repeated-index samples are solved on host threads while the GPU searches --, and the accept rules:
- * the first hypothesis with count >= need wins and ends the search, else the first maximum.  Winner, count and inlier mask
- * equal the reference loop's on the same index table (tests: every RANSAC fixture the reference produced).
+ * rwh_ransac_search, the settle step, and the accept rules: the first hypothesis with count >= need wins and ends the search,
+ * else the first maximum.  Winner, count and inlier mask equal the reference loop's on the same index table (tests: every
+ * RANSAC fixture the reference produced).
+ * The settle step gives the reference's own H (rwh_host_dlt4_svd, re-scored by rwh_score_count) to every hypothesis whose K1 H
+ * may not stand for it in the decision; the repeated-index samples are solved on host threads while the GPU searches.
+ *   'fwd' (round 4): repeated-index / non-finite / RWH_HYP_DEGENERATE samples always; of the others -- every RWH_HYP_ILLCOND
+ *   sample and every hypothesis within 32 counts of the best or of `need` get a count INTERVAL (rwh_score_interval, budgets of 16 /
+ *   64 float32 ulps of natural scale) -- those whose interval is not a point AND reaches the best lower bound or `need`.
+ *   'backward' / 'reproj': every flagged sample and every hypothesis within min(margin_cap, 3 + count / 16) of a decision.
+ * What remains EMPIRICAL in both: that LAPACK's float32 H lies within the budget (resp. that an unflagged K1 count is within the
+ * margin) of K1's -- measured on 13 problem families and ~30 000 soak cases (profiles/r04_lab_notes.txt), not proven.
  *   pts_a, pts_b: m x 2 float32, idx: k x 4 int32 -- HOST arrays (the reference's inputs are host arrays; idx = the first
  *   four columns of numpy's draws, ransac.py:177);
  *   d_ws / h_ws: device workspace and PAGE-LOCKED host workspace of the sizes rwh_ransac_run_layout reports (offsets[11] and
  *   offsets[19]); after the call d_ws holds K1's H (k x 9 float32 at offsets[3]), K2's counts (int32, offsets[4]), K1's flags
  *   (offsets[5]) and the masks (offsets[6]); h_ws holds K2's raw counts (offsets[13]), the flags (offsets[14]) and the counts
  *   after the settle step (offsets[15]);
- *   out: 6 x int32 = winner index (-1: nothing ever scored > 0), early exit (0 / 1), winner's count, hypotheses solved on the
- *   host, settle rounds, samples flagged by K1;  out_mask: ceil(m / 64) x uint64, the winner's inlier bitmask.
+ *   hyp_base (round 4): global index of hypothesis 0 -- a rank of a sharded search passes its slice of the table and its offset;
+ *   out: 8 x int32 = winner index inside this table (-1: nothing ever scored > 0), early exit (0 / 1), winner's count, hypotheses
+ *   solved on the host, settle rounds, samples flagged by K1, hypotheses given an interval, 0;
+ *   out_keys (may be NULL): 2 x uint64, this table's packed keys as rwh_score_count packs them -- (count << 32) | (0xFFFFFFFF -
+ *   (hyp_base + winner)) and 0xFFFFFFFF - (hyp_base + first hypothesis with count >= need), or 0 --: the payload of the ONE
+ *   all-reduce(MAX) of a sharded search;  out_mask: ceil(m / 64) x uint64, the winner's inlier bitmask.
  *   dgesv_ilp64: address of LAPACK dgesv in the same library (numpy.linalg.inv's routine), or NULL: with it the hypotheses
  *   the settle step re-scores under 'backward' / 'reproj' are inverted by rwh_host_inv3 (see rwh_score_count_inv).
- * Synchronises `stream` (its results are host values).  rwh_ransac_run_layout: fills offsets[0 .. 22), returns 22.
+ * Synchronises `stream` (its results are host values).  rwh_ransac_run_layout: fills offsets[0 .. 27), returns 27.
  */
 RWH_API int rwh_ransac_run_layout(int m, int k, long long* offsets, int n_offsets);
 RWH_API int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const int32_t* idx, int k, double th, int loss,
                    int need, int margin_cap, void* dgesdd_ilp64, void* dgesv_ilp64, int threads, void* d_ws, void* h_ws,
-                   int32_t* out, uint64_t* out_mask, void* stream);
+                   int64_t hyp_base, int32_t* out, uint64_t* out_keys, uint64_t* out_mask, void* stream);
 
 /*
  * Fused panorama compositor.  Replaces the body of stitchPanorama (homography.py:288-338) after its canvas

@@ -10,14 +10,14 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "librwh_hip.so")
 
-ABI_VERSION = 2          # RWH_ABI_VERSION of the include/rwh.h this binding was written against
+ABI_VERSION = 3          # RWH_ABI_VERSION of the include/rwh.h this binding was written against
 RWH_U8, RWH_F32, RWH_F64 = 0, 1, 2
 RWH_NEAREST, RWH_BILINEAR = 0, 1
 RWH_LOSS = {"fwd": 0, "backward": 1, "reproj": 2}
 RWH_WARP_ZERO_ORIGIN = 1
 RWH_WARP_EXACT = 2
 RWH_STITCH_FAST = 4
-RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND = 1, 2, 4
+RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND, RWH_HYP_DEGENERATE = 1, 2, 4, 8
 RWH_BATCH_DEVICE_SAMPLING = 1
 RWH_BATCH_EARLY_STOP = 2
 RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT, RWH_TUNE_WARP_FRAMES = 0, 1, 2, 3
@@ -26,7 +26,7 @@ RWH_TUNE_WARP_SHAPE, RWH_TUNE_SCORE_HPW, RWH_TUNE_SCORE_EXACT, RWH_TUNE_WARP_FRA
 EXPORTS = ("rwh_abi_version", "rwh_strerror", "rwh_lab_tune", "rwh_lab_clock_probe", "rwh_warp_backward", "rwh_warp_plan", "rwh_sample_points", "rwh_dlt4_batched",
            "rwh_score_count", "rwh_project_points", "rwh_project_points_ex", "rwh_ransac_search", "rwh_ransac_batched", "rwh_stitch_panorama",
            "rwh_host_dlt4_svd", "rwh_ransac_run", "rwh_ransac_run_layout", "rwh_warp_index_check", "rwh_score_count_inv", "rwh_host_inv3", "rwh_stitch_panorama_rows",
-           "rwh_host_legacy_randint")
+           "rwh_host_legacy_randint", "rwh_score_interval")
 
 
 class RwhUnavailable(RuntimeError):
@@ -88,12 +88,14 @@ def _bind(lib):
     lib.rwh_project_points.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.rwh_host_dlt4_svd.restype = i32
     lib.rwh_host_dlt4_svd.argtypes = [vp, vp, i32, vp, i32, vp, i32, vp]
+    lib.rwh_score_interval.restype = i32
+    lib.rwh_score_interval.argtypes = [vp, vp, i32, vp, vp, vp, i32, f64, f64, f64, f64, vp, vp, vp]
     lib.rwh_host_legacy_randint.restype = i32
     lib.rwh_host_legacy_randint.argtypes = [vp, vp, i64, i64, vp, vp]
     lib.rwh_ransac_run_layout.restype = i32
     lib.rwh_ransac_run_layout.argtypes = [i32, i32, vp, i32]
     lib.rwh_ransac_run.restype = i32
-    lib.rwh_ransac_run.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i32, vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.rwh_ransac_run.argtypes = [vp, vp, i32, vp, i32, f64, i32, i32, i32, vp, vp, i32, vp, vp, i64, vp, vp, vp, vp]
     return lib
 
 

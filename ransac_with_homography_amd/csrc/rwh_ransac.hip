@@ -153,8 +153,14 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
     for (int i = 0; i < 9; ++i) ss = ss + h[i] * h[i];
     // !(x >= t) also catches NaN (0 / 0 scales, inf - inf)
     bool illcond = !(ss <= 1e14);                             // |n[8]| = 1 / sqrt(ss) < 1e-7
+    // RWH_HYP_DEGENERATE (round 4): the part of the ill-conditioned samples whose H says NOTHING about the reference's -- a pivot
+    // below 1e-7 of its column's scale (LAPACK's own null vector is round-off there), |n[8]| < 1e-7, and (below) a nearly
+    // singular H in searches that invert.  The rest of RWH_HYP_ILLCOND (pivot ratios 1e-7 .. 1e-3) is accurate here -- this
+    // elimination is ~1000 x closer to the exact null vector than LAPACK's SVD, profiles/r04_lab_notes.txt -- and under 'fwd' goes
+    // through rwh_score_interval with a wider perturbation budget instead of straight to the host.
+    bool degenerate = illcond;
 #pragma unroll
-    for (int i = 0; i < 5; ++i) illcond |= !(piv_ratio[i] >= 1e-3);
+    for (int i = 0; i < 5; ++i) { illcond |= !(piv_ratio[i] >= 1e-3); degenerate |= !(piv_ratio[i] >= 1e-7); }
     const double rnrm = recip(sqrt(ss));
     float n[9];
 #pragma unroll
@@ -180,9 +186,10 @@ __global__ __launch_bounds__(64) void dlt4_kernel(const float* __restrict__ pa, 
         const double det = (t0 + t1 + t2) - (t3 + t4 + t5);
         const double perm = fabs(t0) + fabs(t1) + fabs(t2) + fabs(t3) + fabs(t4) + fabs(t5);
         illcond |= !(fabs(det) > 1e-6 * perm);
+        degenerate |= !(fabs(det) > 1e-6 * perm);
     }
     if (live) flags[t] = (uint8_t)((repeated || bad_index ? RWH_HYP_REPEATED : 0u) | (finite ? 0u : RWH_HYP_SINGULAR) |
-                                   (illcond ? RWH_HYP_ILLCOND : 0u));
+                                   (illcond ? RWH_HYP_ILLCOND : 0u) | (degenerate ? RWH_HYP_DEGENERATE : 0u));
     // the wave's 64 x 9 floats leave as 9 coalesced 256-byte stores (lane-strided 36-byte records would be 9 scattered ones)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -871,6 +878,80 @@ void launch_score(int words, dim3 grid, hipStream_t s, const float* d_h, const f
 #undef RWH_SCORE
 }
 }  // namespace rwh
+
+
+namespace rwh {
+// ------------------------------------------------------------------------------------------------
+// K2i: the inlier count of a hypothesis as an INTERVAL (round 4; 'fwd' loss).  The reference scores H_L -- LAPACK's null
+// vector rounded to float32 --, the search scored K1's H_K.  The two differ by a few float32 ulps of each entry's NATURAL
+// scale (rows 0 / 1: s, s, s C; row 2: s / C, s / C, s; C = the coordinates' magnitude, s = the largest scale-free entry):
+// measured on 13 problem families, 20 000 samples each, 99.9 % within 13 ulps (profiles/r04_lab_notes.txt).  For every pair
+// this kernel bounds how far its projected point -- hence its error -- can move when every entry of H moves by delta x its
+// natural scale, and counts the pairs that are inliers for EVERY such H (lo) and for SOME such H (hi).  lo == hi: the
+// reference's count and inlier mask are K2's, whatever LAPACK rounded to.  A hypothesis whose hi cannot reach the decision
+// needs no host solve either.  What this replaces is the flat "+- 8 counts" margin of rounds 2-3, which a wild hypothesis
+// (its horizon through the data: one ulp of H moves nine pairs across the threshold) could exceed and a tame one never needs.
+// One wavefront per listed hypothesis; delta0: unflagged rows, delta1: RWH_HYP_ILLCOND rows (K1 accurate, LAPACK noisier).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void score_interval_kernel(const float* __restrict__ hs, const int32_t* __restrict__ rows, int n_rows,
+                                                             const uint8_t* __restrict__ flags, const float* __restrict__ pa,
+                                                             const float* __restrict__ pb, int m, double th, double cscale,
+                                                             double delta0, double delta1, int32_t* __restrict__ lo_out,
+                                                             int32_t* __restrict__ hi_out) {
+    const int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= n_rows) return;
+    const int row = rows ? rows[w] : w;
+    float h[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) h[i] = hs[9 * (size_t)row + i];
+    const double delta = (flags && (flags[row] & RWH_HYP_ILLCOND)) ? delta1 : delta0;
+    const double C = cscale, rC = 1.0 / cscale;
+    double a[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) a[i] = fabs((double)h[i]);
+    double s = fmax(fmax(fmax(a[0], a[1]), fmax(a[3], a[4])), a[8]);
+    s = fmax(s, fmax(fmax(a[2], a[5]) * rC, fmax(a[6], a[7]) * C));
+    double D[9];
+    D[0] = delta * fmax(a[0], s); D[1] = delta * fmax(a[1], s); D[2] = delta * fmax(a[2], s * C);
+    D[3] = delta * fmax(a[3], s); D[4] = delta * fmax(a[4], s); D[5] = delta * fmax(a[5], s * C);
+    D[6] = delta * fmax(a[6], s * rC); D[7] = delta * fmax(a[7], s * rC); D[8] = delta * fmax(a[8], s);
+    int n_in = 0, n_out = 0;
+    for (int j = lane; j < m; j += 64) {
+        const float2 A = reinterpret_cast<const float2*>(pa)[j], B = reinterpret_cast<const float2*>(pb)[j];
+        float px, py, pw;
+        proj(h, A.x, A.y, px, py, pw);                          // the reference's arithmetic (K2's)
+        const float dx = px - B.x, dy = py - B.y;
+        const float err = sqrtf(dx * dx + dy * dy);
+        float a2 = h[6] * A.x; a2 = fmaf(h[7], A.y, a2); a2 = a2 + h[8];
+        const double den = fabs((double)(a2 + 1e-10f));
+        const double ax = fabs((double)A.x), ay = fabs((double)A.y);
+        const double d0 = D[0] * ax + D[1] * ay + D[2], d1 = D[3] * ax + D[4] * ay + D[5], d2 = D[6] * ax + D[7] * ay + D[8];
+        const double room = den - d2;
+        double mg = ((d0 + fabs((double)px) * d2) + (d1 + fabs((double)py) * d2)) / room;
+        // + the float32 evaluation's own round-off at a neighbouring H (a few ulps of the quantities subtracted)
+        mg += 0x1p-21 * (fabs((double)px) + fabs((double)py) + fabs((double)B.x) + fabs((double)B.y));
+        const bool ok = (room > 0.0) & (mg == mg) & (mg < 1e300) & (err == err) & (fabsf(err) < 3.0e38f);
+        const double e = (double)err;
+        n_in += (int)(ok & (e + mg < th));
+        n_out += (int)(ok & (e - mg >= th));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { n_in += __shfl_xor(n_in, o); n_out += __shfl_xor(n_out, o); }
+    if (lane == 0) { lo_out[w] = n_in; hi_out[w] = m - n_out; }
+}
+}  // namespace rwh
+
+extern "C" int rwh_score_interval(const float* d_h, const int32_t* d_rows, int n_rows, const uint8_t* d_flags, const float* d_pts_a,
+                                  const float* d_pts_b, int m, double th, double coord_scale, double delta0, double delta1,
+                                  int32_t* d_lo, int32_t* d_hi, void* stream) {
+    using namespace rwh;
+    if (!d_h || !d_pts_a || !d_pts_b || !d_lo || !d_hi || m <= 0 || n_rows < 0) return RWH_E_INVALID;
+    if (!(coord_scale >= 1.0) || !(delta0 >= 0.0) || !(delta1 >= 0.0)) return RWH_E_INVALID;
+    if (n_rows == 0) return RWH_OK;
+    hipLaunchKernelGGL(score_interval_kernel, dim3((n_rows + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream), d_h, d_rows, n_rows,
+                       d_flags, d_pts_a, d_pts_b, m, th, coord_scale, delta0, delta1, d_lo, d_hi);
+    return check_launch();
+}
 
 extern "C" int rwh_score_count_inv(const float* d_h, const float* d_hinv, const float* d_pts_a, const float* d_pts_b, int m, int k,
                                    double th, int loss, int need, int64_t hyp_base, int32_t* d_counts, uint64_t* d_masks,

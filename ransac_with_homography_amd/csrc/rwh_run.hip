@@ -21,7 +21,8 @@ namespace {
 // sections of the two workspaces (byte offsets, 256-byte aligned)
 enum { D_PA, D_PB, D_IDX, D_H, D_COUNTS, D_FLAGS, D_MASKS, D_BEST, D_HSET, D_CNTSET, D_MASKSET, D_END,
        H_UP, H_COUNTS, H_FLAGS, H_CNTSET, H_HSET, H_MASK, H_ROWS, H_END,
-       D_HINVSET, H_HINVSET, N_OFF };      // (round 3, appended: the settled hypotheses' inverses; both lie before D_END / H_END)
+       D_HINVSET, H_HINVSET,               // (round 3, appended: the settled hypotheses' inverses; both lie before D_END / H_END)
+       D_ROWS, D_LO, D_HI, H_LO, H_HI, N_OFF };   // (round 4: candidate rows and their count intervals, rwh_score_interval)
 
 inline size_t up256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -41,6 +42,9 @@ void layout(int m, int k, long long* off) {
     off[D_CNTSET] = (long long)d; d = up256(d + 4 * K);
     off[D_MASKSET] = (long long)d; d = up256(d + 8 * words * K);
     off[D_HINVSET] = (long long)d; d = up256(d + 36 * K);
+    off[D_ROWS] = (long long)d; d = up256(d + 4 * K);
+    off[D_LO] = (long long)d; d = up256(d + 4 * K);
+    off[D_HI] = (long long)d; d = up256(d + 4 * K);
     off[D_END] = (long long)d;
     size_t h = 0;
     off[H_UP] = (long long)h; h = up256(h + (size_t)(off[D_IDX] - off[D_PA]) + 16 * K);
@@ -51,6 +55,8 @@ void layout(int m, int k, long long* off) {
     off[H_MASK] = (long long)h; h = up256(h + 8 * words);
     off[H_ROWS] = (long long)h; h = up256(h + 16 * K);
     off[H_HINVSET] = (long long)h; h = up256(h + 36 * K);
+    off[H_LO] = (long long)h; h += 4 * K;                 // lo then hi: ONE contiguous readback
+    off[H_HI] = (long long)h; h = up256(h + 4 * K);
     off[H_END] = (long long)h;
 }
 
@@ -63,11 +69,22 @@ extern "C" int rwh_ransac_run_layout(int m, int k, long long* offsets, int n_off
     return N_OFF;
 }
 
+// Settle step under 'fwd' (round 4): which hypotheses need the reference's own solver is decided by COUNT INTERVALS
+// (rwh_score_interval), not by a flat margin.  Candidates -- every RWH_HYP_ILLCOND sample that is not degenerate, every other
+// hypothesis within IV_NEAR counts of the best or of `need` -- get [lo, hi]; host-solved are the repeated-index / non-finite /
+// degenerate samples (their H says nothing) and the candidates that are uncertain (lo < hi) AND able to matter (hi reaches the
+// best lo, or `need`).  IV_DELTA0 / IV_DELTA1: the perturbation budgets, in units of an entry's natural scale, for unflagged /
+// ill-conditioned samples: 16 and 64 float32 ulps (no containment failure at 8 ulps on 13 families x 20 000 samples;
+// profiles/r04_lab_notes.txt).  'backward' / 'reproj' keep the margin rule of rounds 2-3 (an interval through the inverse is
+// too wide to be useful).
+static constexpr int IV_NEAR = 32;
+static constexpr double IV_DELTA0 = 0x1p-20, IV_DELTA1 = 0x1p-18;
+
 extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const int32_t* idx, int k, double th, int loss,
                               int need, int margin_cap, void* dgesdd_ilp64, void* dgesv_ilp64, int threads, void* d_ws, void* h_ws,
-                              int32_t* out, uint64_t* out_mask, void* stream) {
+                              int64_t hyp_base, int32_t* out, uint64_t* out_keys, uint64_t* out_mask, void* stream) {
     if (!pts_a || !pts_b || !idx || !d_ws || !h_ws || !out || !out_mask || !dgesdd_ilp64 || m <= 0 || k < 0) return RWH_E_INVALID;
-    if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ || margin_cap < 0) return RWH_E_INVALID;
+    if (loss < RWH_LOSS_FWD || loss > RWH_LOSS_REPROJ || margin_cap < 0 || hyp_base < 0 || hyp_base + k > 0xFFFFFFFFll) return RWH_E_INVALID;
     for (long long i = 0; i < 4ll * k; ++i)
         if (idx[i] < 0 || idx[i] >= m) return RWH_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -95,12 +112,18 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
     int32_t* h_rows = reinterpret_cast<int32_t*>(Hh + off[H_ROWS]);
     float* d_hinvset = reinterpret_cast<float*>(D + off[D_HINVSET]);
     float* h_hinvset = reinterpret_cast<float*>(Hh + off[H_HINVSET]);
+    int32_t* d_rows = reinterpret_cast<int32_t*>(D + off[D_ROWS]);
+    int32_t* d_lo = reinterpret_cast<int32_t*>(D + off[D_LO]);
+    int32_t* d_hi = reinterpret_cast<int32_t*>(D + off[D_HI]);
+    int32_t* h_lo = reinterpret_cast<int32_t*>(Hh + off[H_LO]);
+    int32_t* h_hi = reinterpret_cast<int32_t*>(Hh + off[H_HI]);
     // 'backward' / 'reproj' project through numpy.linalg.inv(H): the settled hypotheses get THAT inverse (LAPACK dgesv, rwh_host_inv3),
     // not the kernel's own elimination, which rounds apart from it on nearly singular H (rwh.h, rwh_score_count_inv)
     const bool host_inv = loss != RWH_LOSS_FWD && dgesv_ilp64 != nullptr;
 
-    for (int i = 0; i < 6; ++i) out[i] = 0;
+    for (int i = 0; i < 8; ++i) out[i] = 0;
     out[0] = -1;
+    if (out_keys) { out_keys[0] = 0; out_keys[1] = 0; }
     for (int w = 0; w < words; ++w) out_mask[w] = 0;
     if (k == 0) return RWH_OK;
 
@@ -148,12 +171,39 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
         if ((q[0] == q[1]) | (q[0] == q[2]) | (q[0] == q[3]) | (q[1] == q[2]) | (q[1] == q[3]) | (q[2] == q[3])) h_rows[n_rep++] = i;
     }
     st = settle(n_rep);
-    if (st != RWH_OK) return st;
+    if (st != RWH_OK) { (void)hipStreamSynchronize(s); return st; }
     if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
     for (int i = 0; i < k; ++i) cnt[(size_t)i] = h_counts[i];
     absorb(n_rep);
     int n_flagged = 0;
     for (int i = 0; i < k; ++i) n_flagged += h_flags[i] != 0;
+
+    // ---- 'fwd': count intervals for the candidates (see the comment above the function) ------------------------------------
+    double cscale = 1.0;
+    for (long long i = 0; i < 2ll * m; ++i) { const double v = pts_a[i] < 0 ? -(double)pts_a[i] : (double)pts_a[i]; if (v > cscale) cscale = v; }
+    const bool use_iv = loss == RWH_LOSS_FWD && cscale < 1e30;            // (an Inf / NaN coordinate: the margin rule)
+    const unsigned always_bits = use_iv ? (RWH_HYP_REPEATED | RWH_HYP_SINGULAR | RWH_HYP_DEGENERATE) : 0xFFu;
+    std::vector<int> lo, hi;
+    int n_iv = 0;
+    if (use_iv) {
+        lo.assign(cnt.begin(), cnt.end()); hi = lo;                        // not a candidate: its count is taken as it is
+        int best0 = 0;
+        for (int i = 0; i < k; ++i)
+            if (!(h_flags[i] & always_bits) && cnt[(size_t)i] > best0) best0 = cnt[(size_t)i];
+        for (int i = 0; i < k; ++i)
+            if (pos[(size_t)i] < 0 && !(h_flags[i] & always_bits) &&
+                ((h_flags[i] & RWH_HYP_ILLCOND) || cnt[(size_t)i] >= best0 - IV_NEAR || cnt[(size_t)i] >= need - IV_NEAR)) h_rows[n_iv++] = i;
+        if (n_iv) {
+            if (hipMemcpyAsync(d_rows, h_rows, 4 * (size_t)n_iv, hipMemcpyHostToDevice, s) != hipSuccess) return RWH_E_LAUNCH;
+            st = rwh_score_interval(d_H, d_rows, n_iv, d_flags, d_pa, d_pb, m, th, cscale, IV_DELTA0, IV_DELTA1, d_lo, d_hi, s);
+            if (st != RWH_OK) { (void)hipStreamSynchronize(s); return st; }
+            if (hipMemcpyAsync(h_lo, d_lo, 4 * (size_t)n_iv, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipMemcpyAsync(h_hi, d_hi, 4 * (size_t)n_iv, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;
+            if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
+            std::vector<int32_t> rows_iv(h_rows, h_rows + n_iv);          // (h_rows is reused by the rounds below)
+            for (int j = 0; j < n_iv; ++j) { lo[(size_t)rows_iv[(size_t)j]] = h_lo[j]; hi[(size_t)rows_iv[(size_t)j]] = h_hi[j]; }
+        }
+    }
 
     // ---- rounds: settle every hypothesis that can take part in the decision (ransac._settle_on_host, same rules) ----------
     int end = k;
@@ -161,20 +211,33 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
         end = k;
         const int m_need = margin_of(need, margin_cap);
         for (int i = 0; i < k; ++i) {
-            const bool sure = pos[(size_t)i] >= 0 ? cnt[(size_t)i] >= need : (h_flags[i] == 0 && cnt[(size_t)i] >= need + m_need);
+            bool sure;
+            if (pos[(size_t)i] >= 0) sure = cnt[(size_t)i] >= need;
+            else if (use_iv) sure = !(h_flags[i] & always_bits) && lo[(size_t)i] >= need;
+            else sure = h_flags[i] == 0 && cnt[(size_t)i] >= need + m_need;
             if (sure) { end = i + 1; break; }
         }
-        int best = 0;
-        for (int i = 0; i < end; ++i)
-            if ((pos[(size_t)i] >= 0 || h_flags[i] == 0) && cnt[(size_t)i] > best) best = cnt[(size_t)i];
+        int best = 0;                                       // a lower bound of the best count the reference sees in the prefix
+        for (int i = 0; i < end; ++i) {
+            int v = 0;
+            if (pos[(size_t)i] >= 0) v = cnt[(size_t)i];
+            else if (use_iv) v = (h_flags[i] & always_bits) ? 0 : lo[(size_t)i];
+            else v = h_flags[i] == 0 ? cnt[(size_t)i] : 0;
+            if (v > best) best = v;
+        }
         const int m_best = margin_of(best, margin_cap);
         int n_rows = 0;
-        for (int i = 0; i < end; ++i)
-            if (pos[(size_t)i] < 0 && (h_flags[i] != 0 || cnt[(size_t)i] >= best - m_best || cnt[(size_t)i] >= need - m_need)) h_rows[n_rows++] = i;
+        for (int i = 0; i < end; ++i) {
+            if (pos[(size_t)i] >= 0) continue;
+            bool take;
+            if (use_iv) take = (h_flags[i] & always_bits) || (lo[(size_t)i] < hi[(size_t)i] && (hi[(size_t)i] >= best || hi[(size_t)i] >= need));
+            else take = h_flags[i] != 0 || cnt[(size_t)i] >= best - m_best || cnt[(size_t)i] >= need - m_need;
+            if (take) h_rows[n_rows++] = i;
+        }
         if (n_rows == 0) break;
         ++rounds;
         st = settle(n_rows);
-        if (st != RWH_OK) return st;
+        if (st != RWH_OK) { (void)hipStreamSynchronize(s); return st; }
         if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
         absorb(n_rows);
     }
@@ -189,6 +252,14 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
             if (cnt[(size_t)i] > bestc) { bestc = cnt[(size_t)i]; winner = i; }       // strict >: the first index of the maximum
     }
     out[0] = winner; out[1] = early; out[2] = winner >= 0 ? cnt[(size_t)winner] : 0; out[3] = nset; out[4] = rounds; out[5] = n_flagged;
+    out[6] = n_iv;
+    if (out_keys && winner >= 0) {
+        // this slice's packed keys, as K2b packs them (the payload of the one all-reduce of a sharded search): word 0 = count and
+        // inverted GLOBAL index of the slice's winner, word 1 = inverted global index of its first hypothesis that reaches `need`
+        const unsigned long long gi = (unsigned long long)hyp_base + (unsigned long long)winner;
+        out_keys[0] = ((unsigned long long)(unsigned)cnt[(size_t)winner] << 32) | (0xFFFFFFFFull - gi);
+        out_keys[1] = early ? (0xFFFFFFFFull - gi) : 0ull;
+    }
     if (winner >= 0) {
         const uint64_t* src = pos[(size_t)winner] >= 0 ? d_maskset + (size_t)pos[(size_t)winner] * words : d_masks + (size_t)winner * words;
         if (hipMemcpyAsync(h_mask, src, 8 * (size_t)words, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;

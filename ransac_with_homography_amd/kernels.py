@@ -186,6 +186,25 @@ def score_count(H, pts_a, pts_b, th, loss, need, best, hyp_base=0, want_masks=Tr
     return counts, masks, err
 
 
+def score_interval(H, rows, flags, pts_a, pts_b, th, coord_scale, delta0, delta1):
+    """rwh_score_interval: count intervals [lo, hi] of the listed rows of H ([K, 9] float32 on the GPU) under 'fwd' -- the pairs that
+    are inliers for every / for some H within the perturbation budget (delta0, or delta1 for rows flagged RWH_HYP_ILLCOND in
+    `flags`, uint8 [K] on the GPU or None).  rows: host int array.  -> (lo, hi) host int64 arrays."""
+    lib = _lib.load()
+    _dev_check(H, pts_a, pts_b)
+    rows = np.ascontiguousarray(rows, dtype=np.int32)
+    n = int(rows.shape[0])
+    if n == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    d_rows = torch.from_numpy(rows).to(H.device)
+    out = torch.empty((2, n), dtype=torch.int32, device=H.device)
+    check(lib.rwh_score_interval(_ptr(H), _ptr(d_rows), n, _ptr(flags) if flags is not None else None, _ptr(pts_a), _ptr(pts_b),
+                                 int(pts_a.shape[0]), float(th), float(coord_scale), float(delta0), float(delta1), _ptr(out[0]), _ptr(out[1]),
+                                 _lib.stream_ptr()), "rwh_score_interval")
+    o = out.cpu().numpy().astype(np.int64)
+    return o[0], o[1]
+
+
 def host_inverses(H_rows):
     """numpy.linalg.inv of every float32 3 x 3 in `H_rows` ([n, 9] host array) exactly as the reference computes it inside its
     loop (ransac.py:74: float64 LAPACK, cast to float32); a singular matrix gives NaNs instead of numpy's LinAlgError."""
@@ -245,9 +264,9 @@ class RunWorkspace:
     def __init__(self, m, k, device):
         lib = _lib.load()
         self.m, self.k, self.words = int(m), int(k), (int(m) + 63) // 64
-        off = (ctypes.c_longlong * 22)()
-        n = lib.rwh_ransac_run_layout(self.m, self.k, off, 22)
-        if n != 22:
+        off = (ctypes.c_longlong * 27)()
+        n = lib.rwh_ransac_run_layout(self.m, self.k, off, 27)
+        if n != 27:
             check(n if n < 0 else _lib_invalid(), "rwh_ransac_run_layout")
         self.off = list(off)
         self.dev = torch.empty(self.off[self.D_END], dtype=torch.uint8, device=device)
@@ -292,21 +311,25 @@ def _lib_invalid():
     return -1
 
 
-def ransac_run(pts_a, pts_b, idx, th, loss, need, margin_cap, ws, dgesdd, threads, dgesv=None):
+def ransac_run(pts_a, pts_b, idx, th, loss, need, margin_cap, ws, dgesdd, threads, dgesv=None, hyp_base=0, want_keys=False):
     """rwh_ransac_run: upload + search + settle + accept rules in ONE native call.  pts_a / pts_b: float32 [M, 2] HOST arrays,
-    idx: int32 [K, 4] host array.  -> (winner | None, early, count, host_solved, rounds, flagged, mask_words uint64 [words])."""
+    idx: int32 [K, 4] host array (hyp_base: the global index of its first row when it is a slice of a sharded search).
+    -> (winner | None, early, count, host_solved, rounds, flagged, mask_words uint64 [words]); want_keys: + (the slice's two
+    packed keys as int64 [2], hypotheses given a count interval)."""
     lib = _lib.load()
     assert pts_a.dtype == np.float32 and pts_b.dtype == np.float32 and idx.dtype == np.int32
     assert pts_a.flags.c_contiguous and pts_b.flags.c_contiguous and idx.flags.c_contiguous
     assert pts_a.shape == (ws.m, 2) and pts_b.shape == (ws.m, 2) and idx.shape == (ws.k, 4)
-    out = np.zeros(6, dtype=np.int32)
+    out = np.zeros(8, dtype=np.int32)
+    keys = np.zeros(2, dtype=np.uint64)
     mask = np.zeros(ws.words, dtype=np.uint64)
     check(lib.rwh_ransac_run(pts_a.ctypes.data, pts_b.ctypes.data, ws.m, idx.ctypes.data, ws.k, float(th), RWH_LOSS[loss], int(need),
                              int(margin_cap), ctypes.c_void_p(dgesdd), ctypes.c_void_p(dgesv or 0), int(threads), _ptr(ws.dev),
-                             ctypes.c_void_p(ws.host.data_ptr()),
-                             out.ctypes.data, mask.ctypes.data, _lib.stream_ptr()), "rwh_ransac_run")
+                             ctypes.c_void_p(ws.host.data_ptr()), int(hyp_base),
+                             out.ctypes.data, keys.ctypes.data, mask.ctypes.data, _lib.stream_ptr()), "rwh_ransac_run")
     winner = int(out[0])
-    return (winner if winner >= 0 else None), bool(out[1]), int(out[2]), int(out[3]), int(out[4]), int(out[5]), mask
+    res = ((winner if winner >= 0 else None), bool(out[1]), int(out[2]), int(out[3]), int(out[4]), int(out[5]), mask)
+    return res + (keys.view(np.int64), int(out[6])) if want_keys else res
 
 
 class BatchWorkspace:

@@ -223,16 +223,27 @@ def presettle(pa_dev, pb_dev, pa, pb, idx_host, rows, th, method):
     return rows, H, cnt, msk
 
 
-def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, method, margin, stats=None, pre=None):
+# 'fwd' searches (round 4): which hypotheses need the reference's own solver is decided by count INTERVALS (rwh_score_interval),
+# not by a flat margin -- the native driver's rule (csrc/rwh_run.hip), mirrored in `_settle_on_host`.
+IV_NEAR = 32                               # hypotheses within this many counts of the best / of `need` get an interval
+IV_DELTA0, IV_DELTA1 = 2.0 ** -20, 2.0 ** -18     # perturbation budgets (natural scale of an entry): unflagged / RWH_HYP_ILLCOND rows
+
+
+def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, method, margin, stats=None, pre=None, H_dev=None,
+                    flags_dev=None):
     """Accept rules of ransac.py:186-202 over K1/K2's results, exact with respect to the reference's solver.
 
     counts / flags: host copies of K2's counts and K1's flags for the k hypotheses of `idx_host`; `pre`: what `presettle`
     returned (its counts are read here).  Hypotheses are "settled" (H from the host SVD, count + mask from K2 on that H)
     in rounds until every hypothesis that can take part in the decision is settled:
-      * nothing after the first hypothesis that certainly reaches `need` (settled: count >= need; unflagged: count >= need
-        + margin) is ever looked at by the reference (`break`, ransac.py:186-190);
-      * inside that prefix: every flagged hypothesis (repeated index, non-finite, ill-conditioned: K1's H says nothing
-        about the reference's), every unflagged one within `_margin` of `need` or of the best trustworthy count.
+      * nothing after the first hypothesis that certainly reaches `need` is ever looked at by the reference (`break`,
+        ransac.py:186-190);
+      * inside that prefix, 'fwd' with K1's H at hand (`H_dev`): the samples whose H says nothing (repeated index, non-finite,
+        RWH_HYP_DEGENERATE) and, of the candidates -- RWH_HYP_ILLCOND samples, hypotheses within IV_NEAR of the best or of
+        `need`, each with a count interval [lo, hi] from rwh_score_interval --, those whose interval is not a point and reaches
+        the best lower bound or `need`;
+      * 'backward' / 'reproj' (or no H_dev): every flagged hypothesis, every unflagged one within `_margin` of `need` or of
+        the best trustworthy count (the rule of rounds 2-3).
     Usually ONE round beyond `pre`.  Returns (winner | None, early, count, mask_words | None, H_rows, counts): mask_words
     is the winner's uint64 mask if the winner was settled here (None: take K2's own mask for it), H_rows maps settled
     index -> float32[9], counts is the int64 count table with the settled entries replaced."""
@@ -240,23 +251,47 @@ def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, m
     k = counts.shape[0]
     counts = counts.astype(np.int64)
     st = _Settled(k)
+    flags = np.asarray(flags)
     suspect = flags != 0
     n_rounds = 0
     if pre is not None:
         rows, H, cnt, msk = pre
         counts[rows] = cnt.cpu().numpy()
         st.add(rows, H, msk)
+    with np.errstate(invalid="ignore"):
+        cscale = float(max(1.0, np.abs(pa).max())) if pa.size else 1.0
+    use_iv = method == "fwd" and H_dev is not None and cscale < 1e30
+    n_iv = 0
+    if use_iv:
+        always = (flags & (_lib.RWH_HYP_REPEATED | _lib.RWH_HYP_SINGULAR | _lib.RWH_HYP_DEGENERATE)) != 0
+        lo, hi = counts.copy(), counts.copy()              # not a candidate: its count is taken as it is
+        free = ~always
+        best0 = int(counts[free].max()) if free.any() else 0
+        cand0 = np.flatnonzero(~st.done & free & (((flags & _lib.RWH_HYP_ILLCOND) != 0) | (counts >= best0 - IV_NEAR) | (counts >= need - IV_NEAR)))
+        if cand0.size:
+            if flags_dev is None:
+                flags_dev = torch.from_numpy(np.ascontiguousarray(flags, dtype=np.uint8)).to(H_dev.device)
+            lo[cand0], hi[cand0] = kernels.score_interval(H_dev, cand0, flags_dev, pa_dev, pb_dev, th, cscale, IV_DELTA0, IV_DELTA1)
+        n_iv = int(cand0.size)
     while True:
         settled = st.done
-        trusted = settled | ~suspect                      # counts that mean something: the reference's, or K1's within a margin
-        sure = np.where(settled, counts >= need, ~suspect & (counts >= need + _margin(need, margin)))
+        if use_iv:
+            sure = np.where(settled, counts >= need, ~always & (lo >= need))
+        else:
+            sure = np.where(settled, counts >= need, ~suspect & (counts >= need + _margin(need, margin)))
         hit = np.flatnonzero(sure)
         end = int(hit[0]) + 1 if hit.size else k
         c = counts[:end]
-        tc = c[trusted[:end]]
-        best = int(tc.max()) if tc.size else 0
         open_ = ~settled[:end]
-        cand = np.flatnonzero(open_ & (suspect[:end] | (c >= best - _margin(best, margin)) | (c >= need - _margin(need, margin))))
+        if use_iv:
+            v = np.where(settled[:end], c, np.where(always[:end], 0, lo[:end]))
+            best = int(v.max()) if v.size else 0
+            cand = np.flatnonzero(open_ & (always[:end] | ((lo[:end] < hi[:end]) & ((hi[:end] >= best) | (hi[:end] >= need)))))
+        else:
+            trusted = settled | ~suspect                  # counts that mean something: the reference's, or K1's within a margin
+            tc = c[trusted[:end]]
+            best = int(tc.max()) if tc.size else 0
+            cand = np.flatnonzero(open_ & (suspect[:end] | (c >= best - _margin(best, margin)) | (c >= need - _margin(need, margin))))
         if cand.size == 0:
             break
         n_rounds += 1
@@ -268,6 +303,7 @@ def _settle_on_host(pa_dev, pb_dev, pa, pb, idx_host, counts, flags, need, th, m
         stats["host_settled"] = int(st.done.sum())
         stats["host_rounds"] = n_rounds
         stats["flagged"] = int(suspect.sum())
+        stats["intervals"] = n_iv
     hit = np.flatnonzero(c >= need)
     if hit.size:
         w, early = int(hit[0]), True
@@ -467,11 +503,11 @@ class RANSAC(object):
             # the whole driver in ONE native call (rwh_ransac_run, csrc/rwh_run.hip): upload, K1 + K2 + argmax, the settle step
             # (repeated-index samples solved on host threads while the GPU searches), the accept rules
             ws = kernels.RunWorkspace(mx, k, dev)
-            winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words = kernels.ransac_run(
+            winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words, _keys, n_iv = kernels.ransac_run(
                 pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS,
-                dgesv=gesv)
+                dgesv=gesv, want_keys=True)
             counts_host = ws.host_counts(settled=True)
-            stats = {"raw_counts": ws.host_counts(), "host_settled": n_set, "host_rounds": n_rounds, "flagged": n_flagged}
+            stats = {"raw_counts": ws.host_counts(), "host_settled": n_set, "host_rounds": n_rounds, "flagged": n_flagged, "intervals": n_iv}
             Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
             settled_rows = _SettledRows(pa_host, pb_host, idx32)
         else:
@@ -529,7 +565,8 @@ class RANSAC(object):
         counts_host, flags_host = ws.counts_flags()                           # one readback for counts + flags
         stats = {"raw_counts": counts_host.copy()}           # K2 on K1's own H, before the settle step
         winner, early, totalfit, mask_words, settled_rows, counts_host = _settle_on_host(
-            pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need_i, th, method, self.rescore_margin, stats, pre=pre)
+            pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need_i, th, method, self.rescore_margin, stats, pre=pre,
+            H_dev=ws.H, flags_dev=ws.flags)
         if winner is not None and mask_words is None:
             mask_words = ws.masks[winner].cpu().numpy()
         return winner, early, totalfit, mask_words, settled_rows, counts_host, stats, (ws.H, ws.flags, ws.counts, ws.masks)
@@ -640,7 +677,7 @@ def run_batch(datas, th=5, d=50, n=4, k=1000, method="reproj", seed=0, idx=None,
             o0, o1 = int(offsets[p]), int(offsets[p + 1])
             w, early, cnt, words, _, _ = _settle_on_host(pa[o0:o1], pb[o0:o1], pa_host[o0:o1], pb_host[o0:o1], np.asarray(idx[p])[:, :4],
                                                      counts_host[p], flags_host[p], needs_host[p], _weak_threshold(th),
-                                                     method, RESCORE_MARGIN)
+                                                     method, RESCORE_MARGIN, H_dev=ws.H[p], flags_dev=ws.flags[p])
             winners.append((w, None, early)); win_counts.append(cnt); host_masks.append(words)
     else:
         best = ws.best.cpu().numpy()

@@ -29,25 +29,34 @@ def _dist():
 
 
 def gpu_score_slice(pa, pb, idx_slice, th, loss, need, hyp_base):
-    """Product backend: K1 + K2 on this rank's GPU over its slice of the index table, then the slice's accept rules with
-    the reference's solver on every hypothesis that can decide them (`ransac._settle_on_host`: samples with a repeated
-    index, counts within a margin of the slice's best / of `need`).  A hypothesis within the margin of the GLOBAL best
-    is within the margin of its own slice's best, so settling needs no exchange and the path keeps its ONE collective.
-    Returns the slice's two packed keys (include/rwh.h, rwh_score_count) as a 2 x int64 tensor on the GPU."""
+    """Product backend: this rank's slice of the index table through the SAME native driver a one-GPU `RANSAC.run` uses
+    (`rwh_ransac_run` with `hyp_base` = the slice's offset: upload, K1 + K2, the settle step with the reference's solver on
+    every hypothesis that can decide the slice -- repeated-index samples on host threads while the GPU searches --, the accept
+    rules), which returns the slice's two packed keys (round 4; rounds 2-3 ran the step-by-step Python driver here).
+    A hypothesis that can decide the GLOBAL search can decide its own slice (the slice's best is not above the global best),
+    so settling needs no exchange and the path keeps its ONE collective.  Without numpy's LAPACK by address: the Python twin.
+    Returns the keys (include/rwh.h, rwh_score_count) as a 2 x int64 tensor on the GPU."""
     import torch
-    from . import kernels
-    from .ransac import RESCORE_MARGIN, _settle_on_host, presettle, repeated_rows
+    from . import _lapack, kernels
+    from .ransac import HOST_THREADS, RESCORE_MARGIN, _settle_on_host, presettle, repeated_rows
     k = idx_slice.shape[0]
     w0 = w1 = 0
     if k:
         idx_host = np.ascontiguousarray(np.asarray(idx_slice)[:, :4], dtype=np.int32)
-        ws = kernels.SearchWorkspace(k, pa.shape[0], pa.device, want_masks=False)
         pa_host, pb_host = pa.cpu().numpy(), pb.cpu().numpy()          # (before the launch: a copy after it would wait for the search)
+        addr = _lapack.dgesdd_address()
+        gesv = None if loss == "fwd" else _lapack.dgesv_address()
+        if addr is not None and (loss == "fwd" or gesv is not None):
+            ws = kernels.RunWorkspace(pa.shape[0], k, pa.device)
+            res = kernels.ransac_run(np.ascontiguousarray(pa_host, dtype=np.float32), np.ascontiguousarray(pb_host, dtype=np.float32), idx_host,
+                                     th, loss, need, RESCORE_MARGIN, ws, addr, HOST_THREADS, dgesv=gesv, hyp_base=hyp_base, want_keys=True)
+            return torch.from_numpy(res[7].copy()).to(pa.device)
+        ws = kernels.SearchWorkspace(k, pa.shape[0], pa.device, want_masks=False)
         kernels.ransac_search(pa, pb, torch.from_numpy(idx_host).to(pa.device), th, loss, need, ws, hyp_base=hyp_base)
         pre = presettle(pa, pb, pa_host, pb_host, idx_host, np.flatnonzero(repeated_rows(idx_host)), th, loss)   # while the GPU searches
         counts_host, flags_host = ws.counts_flags()
         winner, early, count, _, _, _ = _settle_on_host(pa, pb, pa_host, pb_host, idx_host, counts_host, flags_host, need, th, loss,
-                                                        RESCORE_MARGIN, pre=pre)
+                                                        RESCORE_MARGIN, pre=pre, H_dev=ws.H, flags_dev=ws.flags)
         if winner is not None:
             inv = 0xFFFFFFFF - (hyp_base + winner)
             w0 = (int(count) << 32) | inv

@@ -5,7 +5,7 @@ rounded H agrees with the kernel's on ~all samples, which is all these tests nee
 the count differences)."""
 import numpy as np
 
-RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND = 1, 2, 4
+RWH_HYP_REPEATED, RWH_HYP_SINGULAR, RWH_HYP_ILLCOND, RWH_HYP_DEGENERATE = 1, 2, 4, 8
 
 
 def dlt4(pa, pb, idx, near_singular=False):
@@ -54,6 +54,7 @@ def dlt4(pa, pb, idx, near_singular=False):
         ss = (h * h).sum(1)
         n = (h / np.sqrt(ss)[:, None]).astype(np.float32)
         H = n / n[:, 8:9]
+        degenerate = ~(ss <= 1e14) | ~(ratios >= 1e-7).all(axis=1)
         illcond = ~(ss <= 1e14) | ~(ratios >= 1e-3).all(axis=1)
         finite = np.isfinite(H).all(axis=1)
         # a nearly singular H: |det| against the sum of the six products' magnitudes (rwh_ransac.hip, dlt4_kernel)
@@ -63,7 +64,8 @@ def dlt4(pa, pb, idx, near_singular=False):
         det = (t[0] + t[1] + t[2]) - (t[3] + t[4] + t[5])
         if near_singular:
             illcond |= ~(np.abs(det) > 1e-6 * sum(np.abs(v) for v in t))
+            degenerate |= ~(np.abs(det) > 1e-6 * sum(np.abs(v) for v in t))
     a, b, c, d = (idx[:, i] for i in range(4))
     rep = (a == b) | (a == c) | (a == d) | (b == c) | (b == d) | (c == d)
-    flags = (rep * RWH_HYP_REPEATED + (~finite) * RWH_HYP_SINGULAR + illcond * RWH_HYP_ILLCOND).astype(np.uint8)
+    flags = (rep * RWH_HYP_REPEATED + (~finite) * RWH_HYP_SINGULAR + illcond * RWH_HYP_ILLCOND + degenerate * RWH_HYP_DEGENERATE).astype(np.uint8)
     return np.ascontiguousarray(H, dtype=np.float32), flags

@@ -57,16 +57,18 @@ def test_round3_host_entry_points_without_gpu(lib):
     """rwh_ransac_run_layout (pure arithmetic), argument validation of rwh_ransac_run / rwh_host_dlt4_svd / rwh_lab_clock_probe,
     and the host solver itself -- rwh_host_dlt4_svd needs no GPU: it must reproduce the reference's H on golden samples."""
     from ransac_with_homography_amd import _lapack
-    off = (ctypes.c_longlong * 22)()
-    assert lib.rwh_ransac_run_layout(185, 1500, off, 22) == 22
+    off = (ctypes.c_longlong * 27)()
+    assert lib.rwh_ransac_run_layout(185, 1500, off, 27) == 27 and lib.rwh_ransac_run_layout(185, 1500, off, 22) == -1
     o = list(off)
     assert o[0] == 0 and all(b >= a for a, b in zip(o[:11], o[1:11])) and all(b >= a for a, b in zip(o[12:18], o[13:19]))
     assert o[5] == o[4] + 4 * 1500 and o[14] == o[13] + 4 * 1500            # counts and flags adjacent: one readback
     assert o[11] > 36 * 1500 * 3 and o[19] > 16 * 1500 + 36 * 1500
     assert o[10] < o[20] < o[11] and o[18] < o[21] < o[19]                  # the inverses of the settled rows: inside both workspaces
+    assert o[20] < o[22] < o[23] < o[24] < o[11] and o[21] < o[25] < o[19] and o[26] == o[25] + 4 * 1500   # round 4: candidate rows, count intervals
     assert lib.rwh_ransac_run_layout(185, 1500, off, 21) == -1 and lib.rwh_ransac_run_layout(0, 10, off, 22) == -1
     null = ctypes.c_void_p(0)
-    assert lib.rwh_ransac_run(null, null, 185, null, 10, 5.0, 0, 100, 8, null, null, 1, null, null, null, null, null) == -1
+    assert lib.rwh_ransac_run(null, null, 185, null, 10, 5.0, 0, 100, 8, null, null, 1, null, null, 0, null, null, null, null) == -1
+    assert lib.rwh_score_interval(null, null, 4, null, null, null, 185, 5.0, 1000.0, 1e-6, 1e-5, null, null, null) == -1
     assert lib.rwh_host_dlt4_svd(null, null, 185, null, 4, null, 1, null) == -1
     assert lib.rwh_host_inv3(null, 4, null, null) == -1 and lib.rwh_score_count_inv(null, null, null, null, 4, 4, 1.0, 0, 1, 0, null, null, null, null, null) == -1
     assert lib.rwh_lab_clock_probe(null, 1.0, null) == -1

@@ -193,6 +193,56 @@ def test_illcond_flag_and_settle_on_lattice_problems(oracle_scorer):
         assert stats["host_rounds"] <= 2, (key, stats)
 
 
+def test_interval_settle_rule_on_lattice_problems(oracle_scorer, monkeypatch):
+    """The 'fwd' settle rule of round 4 -- count INTERVALS (rwh_score_interval) decide which hypotheses get the reference's solver,
+    not a flat margin -- on the lattice / cluster fixture g12, with K1 and the interval kernel emulated in numpy
+    (tests/k1_emulation.py, tests/interval_emulation.py) and the oracle as scorer.  Per case: (1) CONTAINMENT, the property the
+    rule stands on: the reference's own count of every hypothesis that is not repeated / non-finite / degenerate lies inside
+    its interval; (2) the settle step returns the reference's winner, count, early-exit flag and inlier list; (3) it hands
+    FEWER hypotheses to the host than the margin rule does."""
+    import interval_emulation as ive
+    from k1_emulation import RWH_HYP_DEGENERATE, RWH_HYP_REPEATED, RWH_HYP_SINGULAR, dlt4
+    monkeypatch.setattr(kernels, "score_interval", lambda H, rows, flags, pa, pb, th, c, d0, d1: ive.score_interval(
+        H.numpy(), rows, None if flags is None else flags.numpy(), pa.numpy(), pb.numpy(), th, c, d0, d1))
+    z = load_golden("g12_illcond")
+    for key in [str(c) for c in z["cases"]]:
+        tag, s, th, d, k, m = key.split("_")
+        if m != "fwd":
+            continue
+        A, B = z["ptsA_" + tag], z["ptsB_" + tag]
+        idx = z[key + "_idx"]
+        ref_counts = z[key + "_hyp_counts"].astype(np.int64)
+        th_f = float(th[2:])
+        H, flags = dlt4(A, B, idx)
+        X, Y = A.T, B.T
+        dev_counts = np.zeros(len(idx), np.int32)
+        with np.errstate(all="ignore"):
+            for i in range(len(idx)):
+                if np.isfinite(H[i]).all():
+                    dev_counts[i] = int((orc.compute_loss(H[i].reshape(3, 3), X, Y, m) < th_f).sum())
+        always = (flags & (RWH_HYP_REPEATED | RWH_HYP_SINGULAR | RWH_HYP_DEGENERATE)) != 0
+        rows = np.flatnonzero(~always)
+        Hs = np.where(np.isfinite(H), H, 0).astype(np.float32)
+        lo, hi = ive.score_interval(Hs, rows, flags, A, B, th_f, max(1.0, float(np.abs(A).max())), impl.IV_DELTA0, impl.IV_DELTA1)
+        assert ((lo <= ref_counts[rows]) & (ref_counts[rows] <= hi)).all(), (key, int(((lo > ref_counts[rows]) | (ref_counts[rows] > hi)).sum()))
+        need = kernels.need_count(A.shape[0], int(d[1:]), 4)
+        out = {}
+        for use_iv in (True, False):
+            stats = {}
+            pre = impl.presettle(torch.from_numpy(A), torch.from_numpy(B), A, B, idx, np.flatnonzero(impl.repeated_rows(idx)), th_f, m)
+            w, early, cnt, words, _, _ = impl._settle_on_host(torch.from_numpy(A), torch.from_numpy(B), A, B, idx, dev_counts, flags, need, th_f, m,
+                                                              impl.RESCORE_MARGIN, stats, pre=pre, H_dev=torch.from_numpy(Hs) if use_iv else None,
+                                                              flags_dev=torch.from_numpy(flags) if use_iv else None)
+            assert w == int(z[key + "_winner"]) and cnt == int(z[key + "_count"]) and early == bool(z[key + "_early"]), (key, use_iv, w, cnt, early)
+            if words is None:
+                inl = np.flatnonzero(orc.compute_loss(H[w].reshape(3, 3), X, Y, m) < th_f)
+            else:
+                inl = np.flatnonzero(np.unpackbits(np.ascontiguousarray(words).view(np.uint8), bitorder="little")[:A.shape[0]])
+            assert np.array_equal(inl, z[key + "_inliers"]), (key, use_iv)
+            out[use_iv] = stats["host_settled"]
+        assert out[True] <= out[False], (key, out)
+
+
 def test_native_legacy_randint_is_numpys_stream():
     """rwh_host_legacy_randint (the index table of RANSAC.run, ransac.py:177) against numpy's own legacy randint: the same
     values, the same dtype for the int64 form, and the global generator left in the same place -- for ranges on and around
