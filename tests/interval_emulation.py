@@ -22,9 +22,12 @@ def score_interval(H, rows, flags, pa, pb, th, coord_scale, delta0, delta1):
         N = np.array([s, s, s * C, s, s, s * C, s / C, s / C, s])
         D = delta * np.maximum(a, N)
         with np.errstate(all="ignore"):
-            a0 = (h[0] * x + h[1] * y) + h[2]
-            a1 = (h[3] * x + h[4] * y) + h[5]
-            a2 = (h[6] * x + h[7] * y) + h[8]
+            # the reference's (OpenBLAS sgemm) order: rounded multiply, ONE fused multiply-add, add; the float64 product
+            # of two float32 values is exact, so rounding its sum once reproduces fmaf up to rare double roundings
+            fmaf = lambda a, b, c: (np.float64(a) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+            a0 = fmaf(h[1], y, h[0] * x) + h[2]
+            a1 = fmaf(h[4], y, h[3] * x) + h[5]
+            a2 = fmaf(h[7], y, h[6] * x) + h[8]
             den = a2 + np.float32(1e-10)
             px, py = a0 / den, a1 / den
             dx, dy = px - tx, py - ty

@@ -1723,6 +1723,79 @@ def test_ransac_run_illcond_samples_vs_reference(gpu):
         assert r.last_run["host_rounds"] <= 3
 
 
+def test_score_interval_kernel_and_dense_cloud_share(gpu):
+    """K2i (rwh_score_interval, round 4): (1) the kernel against its numpy emulation (tests/interval_emulation.py) -- lo / hi
+    equal up to pairs exactly on the boundary, budgets by flag; (2) CONTAINMENT, the property the 'fwd' settle rule stands on, against the
+    reference's solver: for every sample that is not repeated / non-finite / degenerate, the count of LAPACK's H (svd_hypotheses
+    + K2) lies inside [lo, hi] of K1's H -- on dense clouds (Gaussian around (500, 500), sigma 3-40 px, 30 % outliers: the
+    verdict's recipe), two clusters, a lattice and matchespoints; (3) RANSAC.run on those problems equals the oracle's loop and
+    hands LESS THAN 10 % of the hypotheses to the host beyond the repeated-index samples (rounds 2-3: 27-90 % on dense clouds)."""
+    import interval_emulation as ive
+    import ransac as rs
+    from oracle import rwh_oracle as orc
+    from ransac_with_homography_amd import _lib, kernels
+    from ransac_with_homography_amd import ransac as rmod
+    rng = np.random.default_rng(17)
+    HS = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
+
+    def problem(kind, M, sigma):
+        if kind == "cloud": G = rng.normal(500, sigma, (M, 2))
+        elif kind == "two": G = np.array([[400., 450.], [620., 560.]])[rng.integers(0, 2, M)] + rng.normal(0, sigma, (M, 2))
+        else: G = np.stack([rng.integers(0, 12, M) * 37.0, rng.integers(0, 9, M) * 53.0], 1)
+        P = np.c_[G, np.ones(M)] @ HS.T
+        B = P[:, :2] / P[:, 2:3] + rng.normal(0, 1.0, (M, 2))
+        out = rng.random(M) < 0.3
+        B[out] = rng.uniform(B.min(), B.max(), (int(out.sum()), 2))
+        return G.astype(np.float32), B.astype(np.float32)
+    always_bits = _lib.RWH_HYP_REPEATED | _lib.RWH_HYP_SINGULAR | _lib.RWH_HYP_DEGENERATE
+    for kind, M, sigma in (("cloud", 1400, 3), ("cloud", 2000, 10), ("cloud", 2900, 40), ("two", 2000, 5), ("lattice", 600, 0)):
+        A, B = problem(kind, M, sigma)
+        K = 6000
+        idx = rng.integers(0, M, (K, 4)).astype(np.int32)
+        pa, pb = torch.from_numpy(A).to(gpu), torch.from_numpy(B).to(gpu)
+        ws = kernels.SearchWorkspace(K, M, gpu)
+        kernels.ransac_search(pa, pb, torch.from_numpy(idx).to(gpu), 5.0, "fwd", 1 << 30, ws)
+        flags = ws.flags.cpu().numpy()
+        rows = np.flatnonzero((flags & always_bits) == 0)
+        C = max(1.0, float(np.abs(A).max()))
+        lo, hi = kernels.score_interval(ws.H, rows, ws.flags, pa, pb, 5.0, C, rmod.IV_DELTA0, rmod.IV_DELTA1)
+        Hk = ws.H.cpu().numpy()
+        pick = rows[:: max(1, len(rows) // 300)]
+        elo, ehi = ive.score_interval(Hk, pick, flags, A, B, 5.0, C, rmod.IV_DELTA0, rmod.IV_DELTA1)
+        sel = np.searchsorted(rows, pick)
+        # (a pair exactly on e + margin == th may fall either way: the emulation's fmaf is a float64 sum rounded once)
+        assert np.abs(lo[sel] - elo).max() <= 1 and np.abs(hi[sel] - ehi).max() <= 1 and (lo[sel] == elo).mean() > 0.97, (kind, sigma)
+        kc = ws.counts.cpu().numpy()[rows]
+        assert ((lo <= kc) & (kc <= hi)).all()                                   # K2's own count is inside its interval
+        Hl = rmod.svd_hypotheses(A, B, idx[rows])
+        cl, _, _ = kernels.score_count(torch.from_numpy(Hl).to(gpu), pa, pb, 5.0, "fwd", 1 << 30, kernels.new_best(gpu), want_masks=False)
+        cl = cl.cpu().numpy()
+        fin = np.isfinite(Hl).all(axis=1)
+        bad = fin & ((cl < lo) | (cl > hi))
+        assert not bad.any(), (kind, sigma, int(bad.sum()), int(np.abs(cl - kc)[bad].max()))
+        # RANSAC.run against the oracle's sequential loop, and what it costs the host
+        for seed in (1, 2):
+            np.random.seed(seed)
+            with np.errstate(all="ignore"):
+                Ho, inlo, cnto, ito = orc.ransac_run(A.T, B.T, th=5, d=95, n=4, k=400, method="fwd")
+            nxt_o = np.random.randint(0, 1 << 30)
+            np.random.seed(seed)
+            r = rs.RANSAC(rs.HomoModel(th=5, d=95, n=4), k=400)
+            with np.errstate(all="ignore"):
+                Hg, inlg, cntg = r.run([A.T, B.T], method="fwd")
+            assert int(cntg) == int(cnto) and r.last_run["winner"] == ito and np.array_equal(inlg[0], inlo[0]) and np.random.randint(0, 1 << 30) == nxt_o
+        np.random.seed(5)
+        r = rs.RANSAC(rs.HomoModel(th=5, d=95, n=4), k=10000)
+        with np.errstate(all="ignore"):
+            r.run([A.T, B.T], method="fwd")
+        if not r.last_run["early_exit"]:
+            rep = int(rmod.repeated_rows(r.last_run["idx"]).sum())
+            share = (r.last_run["host_settled"] - rep) / 10000.0
+            print("%s M %d sigma %g: flagged by K1 %d, host-solved beyond the %d repeated-index samples: %d of 10000 (%.2f %%), intervals for %d"
+                  % (kind, M, sigma, r.last_run["flagged"], rep, r.last_run["host_settled"] - rep, 100 * share, r.last_run["intervals"]))
+            assert share < 0.10, (kind, sigma, share)
+
+
 def test_ransac_run_n6_vs_reference(gpu, matches):
     """HomoModel(n = 6): six indices per iteration from numpy's stream, the model fitted on the first four, early exit at
     d + 6 (ransac.py:177-190, homography.py:4-14); n < 4 fails like the reference's u[3,0] does.  g13 (reference run)."""
