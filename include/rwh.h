@@ -383,7 +383,9 @@ RWH_API int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, const 
  * inv_h: inv(H); (grid_x0, grid_y0, warp_w, warp_h): wrapPerspective's output grid (min_x, min_y, max_w, max_h);
  * (tsx, tsy) / (qsx, qsy): where the warped imgT / imgQ sit on the canvas_h x canvas_w canvas.
  * blend == 0: paste imgQ over the warped imgT; 1: the 'Rate' alpha blend with blendrate `rate`; 2: the 'Gradient' blend
- * (alpha of imgT = the (x + y) / (w + h) / 2 ramp of homography.py:260-265, alpha of imgQ = 1; always the exact kernel).
+ * (alpha of imgT = the (x + y) / (w + h) / 2 ramp of homography.py:260-265, alpha of imgQ = 1; always the exact kernel);
+ * 3 (round 4): any OTHER truthy `blending` of the reference -- addAlpha then leaves imgT's alpha plane at 0 (homography.py:250-266),
+ * the alpha-weighted mean keeps imgQ / 0 everywhere and the warp only decides where the reference would raise (exact kernel).
  * Any other value: RWH_E_INVALID.
  * flags: RWH_WARP_ZERO_ORIGIN blanks texel (0,0) of imgT first, as bilinear() does to the caller's array;
  * RWH_STITCH_FAST: the staged float32-blend warp kernel with the compositor as its epilogue (rwh::warp_rgb8_comp) instead of

@@ -24,7 +24,8 @@ struct StitchArgs {
     int tsx, tsy, wt, ht;         // warped-T rectangle on the canvas and its size (= the warp's output grid)
     int gx0, gy0;                 // warp grid origin (min_x, min_y): output pixel (c, r) of the warp is at (gx0 + c, gy0 + r)
     int qsx, qsy;                 // imgQ rectangle origin on the canvas
-    int blend;                    // 0 = paste (imgQ over warped imgT), 1 = 'Rate' alpha blend, 2 = 'Gradient' alpha blend
+    int blend;                    // 0 = paste (imgQ over warped imgT), 1 = 'Rate' alpha blend, 2 = 'Gradient' alpha blend,
+                                  // 3 = any other truthy `blending`: addAlpha leaves imgT's alpha plane at 0 (homography.py:250-266)
     float alpha_t;                // 'Rate': float32(rate + 1e-10), the constant alpha plane of imgT
     double ramp_den;              // 'Gradient': w + h of imgT; alpha(x, y) = float32((x + y) / (w + h) * 0.5)
     float alpha_q_in, alpha_q_out;  // canvas alpha inside / outside the imgQ rectangle (float32)
@@ -162,9 +163,9 @@ extern "C" int rwh_stitch_panorama_rows(const void* d_img_t, int t_h, int t_w, c
     if (flags & RWH_WARP_ZERO_ORIGIN) {
         if (hipMemsetAsync(const_cast<void*>(d_img_t), 0, 3, s) != hipSuccess) return RWH_E_LAUNCH;
     }
-    if (blend < 0 || blend > 2) return RWH_E_INVALID;
+    if (blend < 0 || blend > 3) return RWH_E_INVALID;
     if (row_begin == row_end) return RWH_OK;
-    if ((flags & RWH_STITCH_FAST) && blend != 2 && whole) {   // the staged compositor carries constant weights: no ramp (whole canvases only)
+    if ((flags & RWH_STITCH_FAST) && blend < 2 && whole) {   // the staged compositor carries constant weights: no ramp (whole canvases only)
         // the reference's float32 alphas (see below), then the two weight pairs of the mean in float64 -> float32
         const double ta = (double)(float)(rate + 1e-10), qa_in = (double)(float)(1 + 1e-10 - rate), qa_out = (double)(float)1e-10;
         CompArgs c;
@@ -188,8 +189,9 @@ extern "C" int rwh_stitch_panorama_rows(const void* d_img_t, int t_h, int t_w, c
     a.row_begin = row_begin; a.row_end = row_end;
     a.ramp_den = (double)(t_w + t_h);
     // the reference's Python-float arithmetic, then the float32 storage of its arrays
-    a.alpha_t = (float)(rate + 1e-10);                 // addAlpha: rate += 1e-10; imgn[:, :, c] = rate   (float32 array)
-    a.alpha_q_in = blend == 2 ? 1.0f                   // imgn[q-rect, 3] = 1                                 (homography.py:329)
+    a.alpha_t = blend == 3 ? 0.0f                      // a `blending` that is neither 'Rate' nor 'Gradient': the alpha plane stays 0
+                           : (float)(rate + 1e-10);    // addAlpha: rate += 1e-10; imgn[:, :, c] = rate   (float32 array)
+    a.alpha_q_in = blend >= 2 ? 1.0f                   // imgn[q-rect, 3] = 1                                 (homography.py:329)
                               : (float)(1 + 1e-10 - rate);   // imgn[q-rect, 3] = 1 + 1e-10 - blendrate       (float32 array)
     a.alpha_q_out = (float)1e-10;                      // imgn[:, :, 3] += 1e-10 on a float32 zero
     const dim3 grid((canvas_w + 64 * ST_PX - 1) / (64 * ST_PX), (row_end - row_begin + 3) / 4), block(256);

@@ -15,10 +15,10 @@ reference's arithmetic.  There is no CPU implementation of the warp here: withou
 librwh_hip.so and a GPU the warps raise `RwhUnavailable`.
 
 Documented divergences from the reference:
-  * the +1 bilinear tap is clamped where the reference raises IndexError
-    (coordinate exactly on the last column/row; its weight is 0 there);
-  * scan-mode bounds larger than the source are clipped to the source (the
-    reference raises IndexError or reads wrapped rows);
+  * numpy arrays in: a coordinate exactly on the last column / row, or a scan-mode `res` beyond the image, raises the
+    reference's IndexError (`rwh_warp_index_check` tells where the reference would index past the image; fixture g15).
+    Tensors in (the fast kernels): the +1 bilinear tap is clamped instead (its weight is 0 there) and scan-mode bounds
+    larger than the source are clipped to the source;
   * with the fast kernels (torch tensors in, or EXACT = False) the bilinear blend is float32 on
     float64-derived weights (<= 1e-4 relative to the reference's float64 blend, typically 3e-7) and
     uint8 results can differ by 1 LSB where the float64 value sits within ~1e-5 of an integer; with the
@@ -416,32 +416,28 @@ def _stitch_geometry(wt, ht, wq, hq, mx, my):
     return (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (max(tex + 1, qex + 1), max(tey + 1, qey + 1))
 
 
-def _stitch_host(imgQ, imgT, H, blending, blendrate):
-    """stitchPanorama with the compositor on the host (homography.py:296-338 verbatim in structure): used for the
-    blending values the fused kernel does not cover (anything truthy other than 'Rate' / 'Gradient', for which the
-    reference builds an all-zero alpha plane) and for non-uint8 images."""
-    if blending:
-        imgT = addAlpha(imgT, method=blending, rate=blendrate)
-    img_t, mx, my = transformImageH(imgT, H)
-    ht, wt, ct = img_t.shape
-    hq, wq, cq = imgQ.shape
-    (tsx, tsy, tex, tey), (qsx, qsy, qex, qey), (fw, fh) = _stitch_geometry(wt, ht, wq, hq, mx, my)
-    if blending:
-        imgn = np.zeros((fh, fw, ct), dtype=np.float32)
-        imgn[qsy:qey + 1, qsx:qex + 1, :3] = imgQ[:, :, :3].astype(np.float32)
-        imgn[:, :, 3] += 1e-10
-        if blending == 'Rate':
-            imgn[qsy:qey + 1, qsx:qex + 1, 3] = 1 + 1e-10 - blendrate
-        else:
-            imgn[qsy:qey + 1, qsx:qex + 1, 3] = 1
-        win = imgn[tsy:tey + 1, tsx:tex + 1]
-        base = win[:, :, 3:4] + img_t[:, :, 3:4]
-        imgn[tsy:tey + 1, tsx:tex + 1, :3] = (win[:, :, 3:4] / base) * win[:, :, :3] + (img_t[:, :, 3:4] / base) * img_t[:, :, :3]
-        return imgn[:, :, :3].astype(np.uint8)
-    imgn = np.zeros((fh, fw, ct), dtype=np.uint8)
-    imgn[tsy:tey + 1, tsx:tex + 1, :] = img_t
-    imgn[qsy:qey + 1, qsx:qex + 1, :] = imgQ
-    return imgn
+def _as_uint8_image(img, what):
+    """stitchPanorama's kernels take uint8 RGB -- what cv2.imread hands the reference's own pipeline (ransac.py:236-243).  An image
+    of another dtype whose values ARE uint8 values (a uint8 photograph converted to float) gives the reference the same canvas as its
+    uint8 form -- the warp interpolates the same numbers, numpy's assignment into the uint8 canvas truncates the same way -- and is
+    converted; anything else (fractions, values outside 0..255) is refused loudly rather than composited on the host."""
+    if _is_tensor(img):
+        import torch
+        if img.dtype == torch.uint8:
+            return img
+        u = img.to(torch.uint8)
+        if bool((u.to(img.dtype) == img).all()):
+            return u
+    else:
+        a = np.asarray(img)
+        if a.dtype == np.uint8:
+            return img
+        with np.errstate(invalid="ignore"):
+            u = a.astype(np.uint8)
+            if np.array_equal(u.astype(a.dtype), a):
+                return u
+    raise NotImplementedError("stitchPanorama: %s is not uint8 and holds values that are not uint8 values; the MI355X compositor takes "
+                              "uint8 RGB images (the reference composites such images in numpy, homography.py:296-338)" % what)
 
 
 # host arrays: below this many bytes (inputs + result) the plain upload / kernel / download (None: never pipelined).  Measured: a stitch
@@ -604,22 +600,20 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     """Warp imgT by H and composite it with imgQ on a common canvas (homography.py:288-338).  `method` is ignored
     exactly as in the reference (always bilinear).
 
-    uint8 RGB images with blending False, 'Rate' or 'Gradient' run in ONE fused kernel (`rwh_stitch_panorama`): alpha plane,
-    warp, paste / alpha blend per canvas pixel; nothing intermediate (RGBA float32 image, float64 warp, float32 canvas)
-    is materialised.  numpy arrays in (or EXACT = True): the reference's float64 arithmetic, canvas bit-identical to the
+    ONE fused kernel (`rwh_stitch_panorama`): alpha plane, warp, paste / alpha blend per canvas pixel; nothing intermediate (RGBA
+    float32 image, float64 warp, float32 canvas) is materialised.  `blending` False / 'Rate' / 'Gradient' / any other truthy value
+    (for which the reference's addAlpha leaves the alpha plane at 0: blend mode 3) on uint8 RGB images -- or images of another
+    dtype that hold uint8 values, converted; round 4 removed the host compositor that used to take the rest.  numpy arrays in (or EXACT = True): the reference's float64 arithmetic, canvas bit-identical to the
     reference's; torch tensors in (or EXACT = False): the staged fast warp kernel with the compositor as its epilogue,
     canvas within 1 LSB."""
     import torch
-    paste = blending is False or blending is None or blending == 0
-    fused = paste or blending in ('Rate', 'Gradient')
+    paste = not blending                                     # homography.py:298 / 322: `if blending:`
+    if imgQ.shape[2] != 3 or imgT.shape[2] != 3:
+        raise NotImplementedError("stitchPanorama: 3-channel images (the reference pastes a %d-channel warp into its canvas only when both "
+                                  "images have 3 channels, homography.py:296-338)" % imgT.shape[2])
     tens = _is_tensor(imgQ) or _is_tensor(imgT)
-    if not tens:
-        fused = fused and np.asarray(imgQ).dtype == np.uint8 and np.asarray(imgT).dtype == np.uint8
-    else:
-        fused = fused and imgQ.dtype == torch.uint8 and imgT.dtype == torch.uint8
-    fused = fused and imgQ.shape[2] == 3 and imgT.shape[2] == 3
-    if not fused:
-        return _stitch_host(imgQ, imgT, H, blending, blendrate)
+    caller_imgT = imgT
+    imgQ, imgT = _as_uint8_image(imgQ, "imgQ"), _as_uint8_image(imgT, "imgT")
     if blending == 'Rate':
         print(blendrate + 1e-10)   # addAlpha prints the rate it stores (homography.py:257)
     elif blending == 'Gradient':
@@ -633,7 +627,8 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))
     dev = _lib.require_gpu()
     exact = (not tens) if EXACT is None else bool(EXACT)    # numpy in: the bit-identical float64 kernel; tensors in: the fast one
-    mode = 0 if paste else 1 if blending == 'Rate' else 2   # 'Gradient': the alpha ramp, exact kernel only
+    # 'Gradient': the alpha ramp, exact kernel only; any other truthy value: addAlpha leaves the alpha plane at 0 (mode 3)
+    mode = 0 if paste else 1 if blending == 'Rate' else 2 if blending == 'Gradient' else 3
     # large host arrays through the exact kernel: uploads, composition by row tiles and the download overlapped (_stitch_pipelined)
     pipelined = (not tens) and exact and PIPELINE_MIN_BYTES is not None and \
         (np.asarray(imgT).nbytes + np.asarray(imgQ).nbytes + fh * fw * 3) >= PIPELINE_MIN_BYTES
@@ -650,7 +645,7 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     if pipelined:
         res = _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh, fw, mode, blendrate, dev)
         if not blending:
-            _blank_origin(imgT)
+            _blank_origin(caller_imgT)
         bits = int(flag.item())
         if bits:
             kernels.raise_like_reference(bits, (h, w))
@@ -660,7 +655,7 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     if tens:
         return out
     if not blending:
-        _blank_origin(imgT)            # transformImageH -> bilinear blanks the caller's texel (0,0) in the paste path
+        _blank_origin(caller_imgT)     # transformImageH -> bilinear blanks the caller's texel (0,0) in the paste path
     res = _xfer.to_host(out)
     bits = int(flag.item())
     if bits:

@@ -86,24 +86,20 @@ def _weak_threshold(th):
     return float(th)
 
 
-_warned_dtype = False
-
-
 def _points_rows(P):
     """features x observations (2 x M or 3 x M) -> contiguous M x 2 float32.
 
     The search kernels take float32 correspondences -- what the reference's own pipeline hands to RANSAC.run (ransac.py:263-267:
-    np.float32 keypoints).  Other dtypes are cast, with a warning (once): on float64 or integer arrays the reference forms the DLT
-    products and the distances in THAT dtype (homography.py:6-13, ransac.py:78-82), so its last bits -- and with them a borderline
-    inlier -- can differ from what the float32 path returns."""
-    global _warned_dtype
+    np.float32 keypoints; matchespoints.npy is float32).  On float64 or integer arrays the reference forms the DLT products in THAT
+    dtype (homography.py:6-13) and -- even when every value is a float32 value -- the distances in float64 (ransac.py:78-82:
+    float32 projection minus a float64 / integer target), so a borderline pair can fall the other way than in a float32 search.
+    Round 3 cast such arrays with a warning; they are now refused: pass `X.astype(np.float32)` to get the float32 search."""
     P = np.asarray(P)
-    if P.dtype != np.float32 and not _warned_dtype:
-        import warnings
-        _warned_dtype = True
-        warnings.warn("RANSAC: %s correspondences are cast to float32 (the reference's pipeline passes float32; on other dtypes it "
-                      "computes products and distances in that dtype, which this path does not reproduce bit for bit)" % P.dtype, stacklevel=3)
-    return np.ascontiguousarray(P.T[:, :2], dtype=np.float32)
+    if P.dtype != np.float32:
+        raise TypeError("RANSAC: %s correspondences: the MI355X search computes in float32 like the reference's own pipeline "
+                        "(ransac.py:263-267); on this input the reference forms its DLT products in %s and its distances in float64, "
+                        "which this path does not reproduce -- pass float32 arrays (X.astype(np.float32))" % (P.dtype, P.dtype))
+    return np.ascontiguousarray(P.T[:, :2])
 
 
 def legacy_randint_table(m, k, n, want64=True):
