@@ -9,7 +9,6 @@ which gives the same numbers, only slower."""
 import ctypes
 import os
 
-_addr = False
 _addrs = {}
 
 
@@ -45,26 +44,4 @@ def dgesv_address():
 
 
 def dgesdd_address():
-    global _addr
-    if _addr is not False:
-        return _addr
-    _addr = None
-    try:
-        import numpy.linalg._umath_linalg  # noqa: F401  (maps numpy's LAPACK into the process; the name `numpy` itself is unused)
-        paths = set()
-        with open("/proc/self/maps") as f:
-            for line in f:
-                p = line.rsplit(" ", 1)[-1].strip()
-                if "openblas" in os.path.basename(p) and "numpy" in p:
-                    paths.add(p)
-        for p in sorted(paths):
-            lib = ctypes.CDLL(p)                       # already loaded: same handle, same code
-            for name in ("scipy_dgesdd_64_", "dgesdd_64_"):     # ILP64 builds only (the helper passes 64-bit integers)
-                try:
-                    _addr = ctypes.cast(getattr(lib, name), ctypes.c_void_p).value
-                    return _addr
-                except AttributeError:
-                    continue
-    except Exception:
-        _addr = None
-    return _addr
+    return routine_address("dgesdd")

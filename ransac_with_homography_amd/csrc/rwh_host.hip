@@ -58,18 +58,28 @@ void solve_range(dgesdd_t dgesdd, const float* pa, const float* pb, const int32_
 class HostPool {
   public:
     // never destroyed: workers may outlive main().  A forked child gets a pool of its own on first use: the parent's worker
-    // threads do not exist in it (and its mutexes may have been held at the fork).  Two threads racing on the very first call
-    // may create two pools; both work, one is leaked.
+    // threads do not exist in it (and its mutexes may have been held at the fork).  Creation is serialised (two threads on the
+    // very first call used to be able to create two pools, one of them leaked with its workers).
     static HostPool& get() {
         static std::atomic<HostPool*> cur{nullptr};
         static std::atomic<long> owner{0};
+        static std::atomic<long> maker{0};          // pid of the thread creating a pool, 0 = nobody (not a std::mutex: one held
+        const long me = (long)getpid();             //  across a fork would stay locked in the child, whose holder does not exist)
         HostPool* p = cur.load(std::memory_order_acquire);
-        const long me = (long)getpid();
+        if (p && owner.load(std::memory_order_acquire) == me) return *p;
+        for (;;) {
+            long holder = 0;
+            if (maker.compare_exchange_weak(holder, me, std::memory_order_acquire)) break;
+            if (holder != 0 && holder != me && maker.compare_exchange_weak(holder, me, std::memory_order_acquire)) break;   // the parent's, at a fork
+            std::this_thread::yield();
+        }
+        p = cur.load(std::memory_order_acquire);
         if (!p || owner.load(std::memory_order_acquire) != me) {
             p = new HostPool;
             cur.store(p, std::memory_order_release);
             owner.store(me, std::memory_order_release);
         }
+        maker.store(0, std::memory_order_release);
         return *p;
     }
     // run job(chunk) for chunk = 0 .. n_chunks-1 on up to `threads` threads (the caller included)

@@ -147,7 +147,7 @@ def _blank_origin(img):
         img[0, 0, 3] = 0
 
 
-def _to_device(img):
+def _to_device(img, host=None):
     """-> (GPU tensor [H,W,C] uint8|float32, was_numpy, result dtype for nn)."""
     import torch
     dev = _lib.require_gpu()
@@ -158,7 +158,7 @@ def _to_device(img):
         if t.dtype not in (torch.uint8, torch.float32):
             t = t.to(torch.float32)
         return t.contiguous(), False, None
-    src, np_dtype = _host_src(img)
+    src, np_dtype = host if host is not None else _host_src(img)      # (`host`: what _host_src already returned for this image)
     return _xfer.to_device(src, dev), True, np_dtype
 
 
@@ -178,26 +178,31 @@ def _warp(img, H, grid, bound_hw, convert, u8_out):
     if convert not in kernels.INTERP:
         raise KeyError(convert)  # convertfunc[convert], homography.py:179 / 208
     inv_h = np.linalg.inv(np.asarray(H, dtype=np.float64))  # homography.py:172 / 203 (raises LinAlgError)
+    host = None
     if not _is_tensor(img) and PIPELINE_MIN_BYTES is not None:
         # a large host array through the exact kernels: upload, kernel by output-row tiles and download overlapped (_warp_pipelined)
-        a, np_dtype = _host_src(img)
+        a, np_dtype = host = _host_src(img)
         exact = True if EXACT is None else bool(EXACT)
         t_dtype = torch.uint8 if a.dtype == np.uint8 else torch.float32
         out_dtype = t_dtype if convert == "nn" else (torch.uint8 if u8_out else torch.float64 if exact else torch.float32)
         out_bytes = grid.out_h * grid.out_w * a.shape[2] * torch.empty(0, dtype=out_dtype).element_size()
-        if a.shape[0] >= 3 and a.shape[1] >= 3 and a.nbytes + out_bytes >= PIPELINE_MIN_BYTES * PIPELINE_WARP_FACTOR and grid.out_h >= 64:
+        # (the result of a pipelined call is ONE page-locked block: capped like _xfer.to_host's, beyond it the plain path)
+        if a.shape[0] >= 3 and a.shape[1] >= 3 and a.nbytes + out_bytes >= PIPELINE_MIN_BYTES * PIPELINE_WARP_FACTOR and grid.out_h >= 64 \
+                and out_bytes <= _xfer.PINNED_RESULT_MAX:
             dev = _lib.require_gpu()
             a = np.ascontiguousarray(a)
             flag = kernels.warp_index_check(a.shape[:2], inv_h, grid, bound_hw, convert, dev)
             res = _warp_pipelined(a, inv_h, grid, bound_hw, convert, out_dtype, exact, dev)
-            _blank_origin(img)
-            bits = int(flag.item())
-            if bits:
-                kernels.raise_like_reference(bits, a.shape[:2])
-            if convert == "nn":
-                return res if res.dtype == np_dtype else res.astype(np_dtype)
-            return res if (u8_out or res.dtype == np.float64) else res.astype(np.float64)
-    src, was_numpy, np_dtype = _to_device(img)
+            if res is not None:       # (None: page-locked memory for the result could not be had -- the plain path below)
+                _blank_origin(img)
+                bits = int(flag.item())
+                if bits:
+                    kernels.raise_like_reference(bits, a.shape[:2])
+                if convert == "nn":
+                    return res if res.dtype == np_dtype else res.astype(np_dtype)
+                return res if (u8_out or res.dtype == np.float64) else res.astype(np.float64)
+            host = (a, np_dtype)
+    src, was_numpy, np_dtype = _to_device(img, host)
     true_hw = (int(src.shape[0]), int(src.shape[1]))
     if true_hw[0] < 3 or true_hw[1] < 3:      # the kernels want 3 x 3 texels at least: zero rows / columns beyond the bounds, which
         pad = torch.zeros((max(true_hw[0], 3), max(true_hw[1], 3), src.shape[2]), dtype=src.dtype, device=src.device)   # stay (h, w)
@@ -547,7 +552,10 @@ def _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh,
     h, w = int(imgT.shape[0]), int(imgT.shape[1])
     hq, wq = int(imgQ.shape[0]), int(imgQ.shape[1])
     canvas = torch.empty((fh, fw, 3), dtype=torch.uint8, device=dev)
-    host = torch.empty((fh, fw, 3), dtype=torch.uint8, pin_memory=True)
+    try:
+        host = torch.empty((fh, fw, 3), dtype=torch.uint8, pin_memory=True)
+    except RuntimeError:          # no page-locked memory for the canvas: the caller takes the plain path
+        return None
     t_flat = torch.empty(tT.size, dtype=torch.uint8, device=dev)
     q_flat = torch.empty(tQ.size, dtype=torch.uint8, device=dev)
     t_dev, q_dev = t_flat.view(h, w, 3), q_flat.view(hq, wq, 3)
@@ -580,7 +588,10 @@ def _warp_pipelined(a, inv_h, grid, bound_hw, convert, out_dtype, exact, dev):
     src = s_flat.view(t_dtype).view(h, w, c)
     oh, ow = grid.out_h, grid.out_w
     result = torch.empty((oh, ow, c), dtype=out_dtype, device=dev)
-    host = torch.empty((oh, ow, c), dtype=out_dtype, pin_memory=True)
+    try:
+        host = torch.empty((oh, ow, c), dtype=out_dtype, pin_memory=True)
+    except RuntimeError:          # no page-locked memory for a result of this size: the caller takes the plain path
+        return None
     nt = int(max(1, min(24, oh // 64)))
     bounds = np.linspace(0, oh, nt + 1).astype(np.int64)
     ih = np.asarray(inv_h, dtype=np.float64)
@@ -630,7 +641,7 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     # 'Gradient': the alpha ramp, exact kernel only; any other truthy value: addAlpha leaves the alpha plane at 0 (mode 3)
     mode = 0 if paste else 1 if blending == 'Rate' else 2 if blending == 'Gradient' else 3
     # large host arrays through the exact kernel: uploads, composition by row tiles and the download overlapped (_stitch_pipelined)
-    pipelined = (not tens) and exact and PIPELINE_MIN_BYTES is not None and \
+    pipelined = (not tens) and exact and PIPELINE_MIN_BYTES is not None and fh * fw * 3 <= _xfer.PINNED_RESULT_MAX and \
         (np.asarray(imgT).nbytes + np.asarray(imgQ).nbytes + fh * fw * 3) >= PIPELINE_MIN_BYTES
     if tens:
         t_dev = imgT.to(dev).contiguous()
@@ -644,12 +655,15 @@ def stitchPanorama(imgQ, imgT, H, method='bilinear', blending=False, blendrate=0
     flag = None if tens else kernels.warp_index_check((h, w), inv_h, kernels.Grid(mx, mx + wt - 1, wt, my, my + ht - 1, ht), (h, w), "bilinear", dev)
     if pipelined:
         res = _stitch_pipelined(imgQ, imgT, inv_h, mx, my, wt, ht, tsx, tsy, qsx, qsy, fh, fw, mode, blendrate, dev)
-        if not blending:
-            _blank_origin(caller_imgT)
-        bits = int(flag.item())
-        if bits:
-            kernels.raise_like_reference(bits, (h, w))
-        return res
+        if res is not None:
+            if not blending:
+                _blank_origin(caller_imgT)
+            bits = int(flag.item())
+            if bits:
+                kernels.raise_like_reference(bits, (h, w))
+            return res
+        t_dev = _xfer.to_device(imgT, dev)      # (no page-locked memory for the canvas: upload / kernel / download)
+        q_dev = _xfer.to_device(imgQ, dev)
     out = kernels.stitch_panorama(t_dev, q_dev, inv_h, (mx, my), (wt, ht), (tsx, tsy), (qsx, qsy), (fh, fw),
                                   mode, blendrate, zero_origin=True, fast=not exact)
     if tens:

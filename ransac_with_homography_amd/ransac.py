@@ -499,9 +499,17 @@ class RANSAC(object):
             # the whole driver in ONE native call (rwh_ransac_run, csrc/rwh_run.hip): upload, K1 + K2 + argmax, the settle step
             # (repeated-index samples solved on host threads while the GPU searches), the accept rules
             ws = kernels.RunWorkspace(mx, k, dev)
-            winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words, _keys, n_iv = kernels.ransac_run(
-                pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS,
-                dgesv=gesv, want_keys=True)
+            try:
+                winner, early, totalfit, n_set, n_rounds, n_flagged, mask_words, _keys, n_iv = kernels.ransac_run(
+                    pa_host, pb_host, idx32, th, method, need_i, self.rescore_margin, ws, addr, HOST_THREADS,
+                    dgesv=gesv, want_keys=True)
+            except _lib.RwhError:
+                # LAPACK refused a sample (info != 0: e.g. an Inf coordinate times 0 is a NaN in the DLT matrix): the step-by-step
+                # twin reaches numpy.linalg.svd, which raises the reference's LinAlgError for it
+                ws = None
+        else:
+            ws = None
+        if ws is not None:
             counts_host = ws.host_counts(settled=True)
             stats = {"raw_counts": ws.host_counts(), "host_settled": n_set, "host_rounds": n_rounds, "flagged": n_flagged, "intervals": n_iv}
             Hs, flags, counts, masks = ws.H, ws.flags, ws.counts, ws.masks
