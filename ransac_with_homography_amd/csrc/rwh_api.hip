@@ -15,7 +15,7 @@ extern "C" int rwh_lab_tune(int knob, int value) {
     if (knob == RWH_TUNE_WARP_SHAPE && (value == 0 || (value >= 5 && value <= 7) || value == 13 || value == 14)) { rwh::g_force_warp_shape = value; return RWH_OK; }
     if (knob == RWH_TUNE_SCORE_HPW && value >= 0 && value <= 64) { rwh::g_force_score_hpw = value; return RWH_OK; }
     if (knob == RWH_TUNE_SCORE_EXACT && (value == 0 || value == 1)) { rwh::g_score_exact_only = value; return RWH_OK; }
-    if (knob == RWH_TUNE_WARP_FRAMES && value >= 0 && value <= 64) { rwh::g_force_warp_frames = value; return RWH_OK; }
+    if (knob == RWH_TUNE_WARP_FRAMES && ((value >= 0 && value <= 64) || (value >= 102 && value <= 164))) { rwh::g_force_warp_frames = value; return RWH_OK; }
     return RWH_E_INVALID;
 }
 

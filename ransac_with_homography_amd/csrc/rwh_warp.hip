@@ -491,7 +491,24 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     if ((size_t)w.rows * (size_t)w.out_w * (size_t)channels * dst_esz >= (1ull << 32)) return RWH_E_UNSUPPORTED;  // 32-bit lane offsets
     FastArgs a;
     a.src = w.src; a.dst = w.dst; a.src_img_stride = w.src_img_stride; a.dst_img_stride = w.dst_img_stride;
-    a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w;
+    a.src_h = w.src_h; a.src_w = w.src_w; a.bound_h = w.bound_h; a.bound_w = w.bound_w; a.out_w = w.out_w; a.pitch_w = w.out_w;
+    // a thin ragged right edge (1 .. STRIP_MAX columns past a multiple of 128) is left to warp_rgb8_strip (rwh_warp_rgb8.h): the
+    // bilinear 8 px kernels then cover whole tiles only.  A function of out_w alone: shards, batches, tables and shapes agree.
+    const int strip = (px8 && !nn && !custom && !comp && channels == 3 && w.out_w >= 256 && w.out_w % 128 >= 1 && w.out_w % 128 <= STRIP_MAX)
+                          ? w.out_w % 128 : 0;
+    a.out_w = w.out_w - strip;
+    auto launch_strip = [&](const CoefTab* tab, int count) -> int {
+        if (!strip || g_plan_buf) return RWH_OK;
+        const dim3 sgrid((unsigned)((w.rows + 255) / 256), (unsigned)count);
+        if (tab) {
+            if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_strip_tab<unsigned char>, sgrid, dim3(256), 0, s, a, *tab);
+            else hipLaunchKernelGGL(warp_rgb8_strip_tab<float>, sgrid, dim3(256), 0, s, a, *tab);
+        } else {
+            if (dst_dtype == RWH_U8) hipLaunchKernelGGL(warp_rgb8_strip<unsigned char>, sgrid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL(warp_rgb8_strip<float>, sgrid, dim3(256), 0, s, a);
+        }
+        return check_launch();
+    };
     a.row_begin = w.row_begin; a.rows = w.rows;
     a.gx0 = w.x0; a.gstep_x = w.step_x; a.gx_last = w.x_last; a.gy0 = w.y0; a.gstep_y = w.step_y; a.gy_last = w.y_last;
     a.out_h = w.out_h;
@@ -517,7 +534,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
     const double xm = MAGIC + (double)(w.bound_w - 1), ym = MAGIC + (double)(w.bound_h - 1);
     __builtin_memcpy(&a.xmax_bits, &xm, 8);
     __builtin_memcpy(&a.ymax_bits, &ym, 8);
-    a.tiles_x = (unsigned)(px8 ? (w.out_w + 127) / 128 : (w.out_w + 255) / 256);
+    a.tiles_x = (unsigned)(px8 ? (a.out_w + 127) / 128 : (a.out_w + 255) / 256);
     a.group = group;   // free parameter of a tools/warp_lab custom kernel
     a.tiles_y = (unsigned)(px8 ? (w.rows + 15) / 16 : (w.rows + 3) / 4);
     const bool u8 = dst_dtype == RWH_U8;
@@ -561,7 +578,8 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         // (profiles/r04_lab_notes.txt) gives +3 % on 4K x 32, +2 % on 1080p x 512 and -3 % on 8K x 8 at its best setting (3-4
         // frames): this warp is bound by the memory system's throughput on its access pattern, not by its arithmetic.
         if (px8 && !nn && !custom && !halves && u8 && batch >= 2 && g_force_warp_frames >= 2) {
-            const int want = g_force_warp_frames;
+            const int want = g_force_warp_frames % 100;
+            const bool block_window = g_force_warp_frames >= 100;      // 100 + n: one staging window per block (warp_rgb8_fast8mb)
             const int F = want < batch ? want : batch;
             const unsigned long long ntiles = (unsigned long long)a.tiles_x * a.tiles_y, groups = ((unsigned)batch + F - 1) / F;
             const unsigned long long mnb = ntiles * groups;
@@ -569,10 +587,12 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
             if (mnb < (1ull << 31) / 8 && (ntiles == 1 || magic)) {
                 a.mf_frames = F; a.mf_batch = batch; a.ntiles = (unsigned)ntiles; a.ntiles_magic = magic;
                 a.mf_nblocks = (unsigned)mnb; a.mf_cpx = (a.mf_nblocks + 7u) / 8u;
-                if (plan_only("rwh::warp_rgb8_fast8m<%.0s%d>", "", shape)) return RWH_OK;
-                void (*mk)(const FastArgs) = shape == 7 ? warp_rgb8_fast8m<7> : shape == 6 ? warp_rgb8_fast8m<6> : warp_rgb8_fast8m<5>;
+                if (plan_only(block_window ? "rwh::warp_rgb8_fast8mb<%.0s%d>" : "rwh::warp_rgb8_fast8m<%.0s%d>", "", shape)) return RWH_OK;
+                void (*mk)(const FastArgs) = block_window ? (shape == 7 ? warp_rgb8_fast8mb<7> : shape == 6 ? warp_rgb8_fast8mb<6> : warp_rgb8_fast8mb<5>)
+                                                          : (shape == 7 ? warp_rgb8_fast8m<7> : shape == 6 ? warp_rgb8_fast8m<6> : warp_rgb8_fast8m<5>);
                 hipLaunchKernelGGL(mk, dim3(8u * a.mf_cpx), block, 0, s, a);
-                return check_launch();
+                if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
+                return launch_strip(nullptr, batch);
             }
         }
         if (custom ? false : nn ? plan_only("rwh::warp_rgb8_nn<%.0s%d>", "", shape)
@@ -581,7 +601,8 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
                                  : plan_only("rwh::warp_rgb8_fast8<%s, %d>", u8 ? "unsigned char" : "float", shape))
             return RWH_OK;
         hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a);
-        return check_launch();
+        if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
+        return launch_strip(nullptr, batch);
     }
     // one homography per image: per shape, TAB_N images per launch with their coefficients as a second kernel argument
     for (int code = 15; code >= 5; --code) {
@@ -609,6 +630,7 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
                 if (hv ? plan_only("rwh::warp_rgb8_fast8h_tab<%.0s%d>", "", sh) : nn ? plan_only("rwh::warp_rgb8_nn_tab<%.0s%d>", "", sh) : plan_only("rwh::warp_rgb8_fast8_tab<%s, %d>", u8 ? "unsigned char" : "float", sh)) { count = 0; continue; }
                 hipLaunchKernelGGL(kern, dim3(8u * a.cpx), block, 0, s, a, tab);
                 if (check_launch() != RWH_OK) return RWH_E_LAUNCH;
+                if (!nn && launch_strip(&tab, count) != RWH_OK) return RWH_E_LAUNCH;
                 count = 0;
             }
         }

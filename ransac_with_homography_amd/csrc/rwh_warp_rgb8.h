@@ -69,7 +69,9 @@ struct FastArgs {
     Coef c;
     double dxs[3][3];                                    // 4 px kernel: dxs[j-1] = j * (cx[2], cy[2], cw[2])
     unsigned long long xmax_bits, ymax_bits;             // bit patterns of MAGIC + (bound_w-1), MAGIC + (bound_h-1)
-    int src_h, src_w, bound_h, bound_w, out_w;
+    int src_h, src_w, bound_h, bound_w, out_w;          // out_w: the columns this launch's tiles cover (its first columns of the row)
+    int pitch_w;                                         // pixels per output row in memory (round 4: a thin ragged right edge is left to
+                                                         //  warp_rgb8_strip, so the tiled launch may cover fewer columns than the row has)
     int row_begin, rows;                                 // produce output rows [row_begin, row_begin+rows)
     unsigned tiles_x, tiles_y, nblocks, cpx;
     unsigned tiles_x_magic, tiles_y_magic;               // floor(n/d) = umulhi(n, magic) for n < nblocks
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(256, RWH_F4_WAVES) void warp_rgb8_fast(const FastAr
     const unsigned char* simg = a.src + (long long)img * a.src_img_stride;       // uniform
     unsigned char* dimg = a.dst + (long long)img * a.dst_img_stride;              // uniform
     // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
-    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
+    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.pitch_w + (uint32_t)c0p) * (uint32_t)(3 * sizeof(DstT)));
 
     // ---- source coordinates of the lane's 4 pixels -----------------------------------------------
     const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
@@ -747,7 +749,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;       // uniform
     unsigned char* dimg = a.dst + (long long)img_mem * a.dst_img_stride;              // uniform
     // 32-bit lane offset from a uniform base (host guarantees rows*out_w*3*sizeof(DstT) < 2^32)
-    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * (uint32_t)(CH * sizeof(DstT)));
+    DstT* drow = reinterpret_cast<DstT*>(dimg + ((uint32_t)rr * (uint32_t)a.pitch_w + (uint32_t)c0p) * (uint32_t)(CH * sizeof(DstT)));
     const uint32_t pitch = (uint32_t)a.src_w * (uint32_t)CH;
 
     // ---- compositor: where does this wave's patch lie relative to the rectangles T and Q? (uniform) ---------------------
@@ -1372,7 +1374,7 @@ __device__ __forceinline__ void fast8m_body(const FastArgs& a) {
     const uint32_t goff = mad24_s((uint32_t)srow, pitch, mul24_12((uint32_t)scol));
     const unsigned char* gsrc = a.src + (long long)f0 * a.src_img_stride + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
     unsigned char* gdst = a.dst + (long long)f0 * a.dst_img_stride;                                                            // uniform
-    const uint32_t doff = ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * 3u;
+    const uint32_t doff = ((uint32_t)rr * (uint32_t)a.pitch_w + (uint32_t)c0p) * 3u;
     // Staging loads spelled in assembly: scalar row base + per-lane offset (no address VALU), the lane / pass predicate as an
     // exec mask INSIDE the statement.  Left to hipcc, five conditionally loaded 12-byte tuples that stay live across the blend
     // all land in ONE register triple and are copied out one by one behind an s_waitcnt vmcnt(0) each: no overlap at all.
@@ -1539,11 +1541,295 @@ __device__ __forceinline__ void fast8m_body(const FastArgs& a) {
     }
 #endif
 }
+// ---- the same with ONE staging window per BLOCK (lab kernel, rwh_lab_tune(RWH_TUNE_WARP_FRAMES, 100 + n)) ---------------------
+// tools/pattern_probe.hip (the warp's memory patterns without its arithmetic, 32 x 4K frames): loads of four wave-private
+// windows + the 96-byte-segment stores 0.3147 ms -- a plain copy of the same bytes: 0.3022 --; ONE window per 128 x 16 tile
+// (132 x 18 texels for 2048 pixels instead of 4 x 66 x 10) + the same stores 0.2793 ms.  The halo is what the load path pays for.
+// Here the block's 256 threads stage the union of the four patches' footprints into one RGBX slab (fixed lane map: slot c = thread
+// + 256 p -> row c / BCH, chunk c % BCH), the waves take their taps from it; two block barriers per frame (slab free / slab ready),
+// which the multi-frame loop can afford: its per-frame arithmetic is half the one-frame kernel's.  Blocks with a patch that is not
+// strictly interior, or whose union does not fit BROWS x BCH chunks, run the one-frame body frame by frame (all four waves).
+constexpr int BCH = 36, BROWS = 22;                     // block window: 144 texels x 22 rows
+// block barrier that orders LDS traffic only (__syncthreads' fence also waits for every outstanding global load and store:
+// the prefetched chunks of the next frame, the stores of the previous one)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" : : : "memory"); }
+template <int LOG_PW>
+__device__ __forceinline__ void fast8mb_body(const FastArgs& a) {
+    constexpr int PW = 1 << LOG_PW, PH = 512 / PW, LPR = PW / 8, WX = 128 / PW;
+    using Win = F8Window<LOG_PW>;
+    constexpr uint32_t lpitch = BCH * 16 + RWH_F8M_SKEW;
+    constexpr int SLABW = ((Win::ROWS * (int)(Win::LPITCH + RWH_F8M_SKEW) + 15) / 16) * 16;      // per wave, as fast8m_body (the fallback's)
+    static_assert(4 * SLABW >= BROWS * (int)lpitch + 128, "the block window lives in the four waves' slabs");
+    constexpr float WS = W_SCALE * MIX_S, WO = W_ONE * MIX_S, WC = MIX_S;
+    unsigned char* const slab0 = wave_slabs<SLABW>();
+
+    const unsigned b = blockIdx.x;
+    const unsigned logical = (b & 7u) * a.mf_cpx + (b >> 3);
+    if (logical >= a.mf_nblocks) return;                                             // (block-uniform)
+    const unsigned g = a.ntiles_magic ? __umulhi(logical, a.ntiles_magic) : (a.ntiles == 1u ? logical : 0u);
+    const unsigned ti = logical - g * a.ntiles;
+    const int f0 = (int)g * a.mf_frames, f1 = min(f0 + a.mf_frames, a.mf_batch);
+    const unsigned ty = a.tiles_x_magic ? __umulhi(ti, a.tiles_x_magic) : ti;
+    const unsigned tx = ti - ty * a.tiles_x;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const Coef& co = a.c;
+    const int lane = threadIdx.x & 63;
+    const int prow = lane / LPR, pq = lane % LPR;
+    const int wave_x = (wave % WX) * PW, wave_y = (wave / WX) * PH;
+    const int rr_raw = (int)ty * 16 + wave_y + prow;
+    const int rr = min(rr_raw, a.rows - 1);
+    const int tcol0 = (int)tx * 128;
+    const int tcol = min(tcol0, a.out_w - 128);
+    const int tshift = tcol0 - tcol;
+    const int lcol = wave_x + pq * 4;
+    const int c0p = tcol + lcol;
+    const bool store_any = rr_raw < a.rows;
+    const uint32_t pitch = (uint32_t)a.src_w * 3u;
+
+    // ---- the lane's end pixels and the wave's footprint: fast8_body's arithmetic ---------------------------------------------
+    const double fr = (double)(a.row_begin + rr), fc = (double)c0p;
+    const double X0 = fma(fc, co.cx[2], fma(fr, co.cx[1], co.cx[0]));
+    const double Y0 = fma(fc, co.cy[2], fma(fr, co.cy[1], co.cy[0]));
+    const double W0 = fma(fc, co.cw[2], fma(fr, co.cw[1], co.cw[0]));
+    uint32_t ehx[2], ehy[2], elx[2], ely[2];
+    bool wpos;
+    {
+        const double X7 = X0 + co.dxs8[6][0], Y7 = Y0 + co.dxs8[6][1], W7 = W0 + co.dxs8[6][2];
+        double r0 = __builtin_amdgcn_rcp(W0); r0 = fma(fma(-W0, r0, 1.0), r0, r0);
+        double r7 = __builtin_amdgcn_rcp(W7); r7 = fma(fma(-W7, r7, 1.0), r7, r7);
+        const double ux0 = fma(X0, r0, MAGIC), uy0 = fma(Y0, r0, MAGIC), ux7 = fma(X7, r7, MAGIC), uy7 = fma(Y7, r7, MAGIC);
+        ehx[0] = hi32(ux0); elx[0] = lo32(ux0); ehy[0] = hi32(uy0); ely[0] = lo32(uy0);
+        ehx[1] = hi32(ux7); elx[1] = lo32(ux7); ehy[1] = hi32(uy7); ely[1] = lo32(uy7);
+        const int h0 = (int)hi32(W0), h7 = (int)hi32(W7);
+        wpos = __all((int)(h0 > 0x2D300000) & (int)(h0 < 0x52B00000) & (int)(h7 > 0x2D300000) & (int)(h7 < 0x52B00000));
+    }
+    const int x0 = (int)__builtin_amdgcn_readlane(ehx[0], 0), x1 = (int)__builtin_amdgcn_readlane(ehx[1], LPR - 1);
+    const int x2 = (int)__builtin_amdgcn_readlane(ehx[0], 64 - LPR), x3 = (int)__builtin_amdgcn_readlane(ehx[1], 63);
+    const int y0 = (int)__builtin_amdgcn_readlane(ehy[0], 0), y1 = (int)__builtin_amdgcn_readlane(ehy[1], LPR - 1);
+    const int y2 = (int)__builtin_amdgcn_readlane(ehy[0], 64 - LPR), y3 = (int)__builtin_amdgcn_readlane(ehy[1], 63);
+    const int whxmn = smin(smin(x0, x1), smin(x2, x3)) & ~3, whxmx = smax(smax(x0, x1), smax(x2, x3));
+    const int whymn = smin(smin(y0, y1), smin(y2, y3)), whymx = smax(smax(y0, y1), smax(y2, y3));
+    {
+        const int xmn = (int)((uint32_t)smax(whxmn, 0) - MAGIC_HI), xmx = (int)((uint32_t)smax(whxmx, 0) - MAGIC_HI);
+        const int ymn = (int)((uint32_t)smax(whymn, 0) - MAGIC_HI), ymx = (int)((uint32_t)smax(whymx, 0) - MAGIC_HI);
+        const bool interior = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2));
+        // ---- the block's window = the union of its four patches' footprints (through LDS; block-uniform afterwards) -------------
+        int* red = reinterpret_cast<int*>(slab0);
+        if (lane == 0) { red[5 * wave] = whxmn; red[5 * wave + 1] = whxmx; red[5 * wave + 2] = whymn; red[5 * wave + 3] = whymx; red[5 * wave + 4] = interior ? 1 : 0; }
+    }
+    __syncthreads();
+    int hxmn, hxmx, hymn, hymx, all_in;
+    {
+        const int* red = reinterpret_cast<const int*>(slab0);
+        hxmn = min(min(red[0], red[5]), min(red[10], red[15])); hxmx = max(max(red[1], red[6]), max(red[11], red[16]));
+        hymn = min(min(red[2], red[7]), min(red[12], red[17])); hymx = max(max(red[3], red[8]), max(red[13], red[18]));
+        all_in = red[4] & red[9] & red[14] & red[19];
+        hxmn = __builtin_amdgcn_readfirstlane(hxmn); hxmx = __builtin_amdgcn_readfirstlane(hxmx);
+        hymn = __builtin_amdgcn_readfirstlane(hymn); hymx = __builtin_amdgcn_readfirstlane(hymx);
+        all_in = __builtin_amdgcn_readfirstlane(all_in);
+    }
+    __syncthreads();                                           // (the scratch words are slab bytes: read by all before anyone stages)
+    const int xmn = (int)((uint32_t)hxmn - MAGIC_HI), xmx = (int)((uint32_t)hxmx - MAGIC_HI);          // all_in: the hi dwords are >= MAGIC_HI
+    const int ymn = (int)((uint32_t)hymn - MAGIC_HI), ymx = (int)((uint32_t)hymx - MAGIC_HI);
+    const int nrows = ymx - ymn + 2, C = (xmx - xmn + 5) >> 2;
+    if (!(all_in && nrows <= BROWS && C <= BCH)) {            // block-uniform: the one-frame body, frame by frame, every wave its patch
+        const int own_from = (int)tx * 128 - min((int)tx * 128, a.out_w - 128);
+        if ((wave % WX + 1) * PW <= own_from) return;
+        for (int f = f0; f < f1; ++f) fast8_body<unsigned char, LOG_PW, false, 3, false, true>(a, nullptr, nullptr, (int)((unsigned)f * a.ntiles + ti), slab0);
+        return;
+    }
+
+    // ---- staging slots of this thread: c = thread + 256 p -> (row c / BCH, chunk c % BCH) of the block window ---------------
+    constexpr int SLOTS = (BROWS * BCH + 255) / 256;
+    uint32_t goff[SLOTS], wl[SLOTS];
+    unsigned long long smask[SLOTS];
+    bool sact[SLOTS];
+#pragma unroll
+    for (int p = 0; p < SLOTS; ++p) {
+        const int c = (int)threadIdx.x + 256 * p, r = c / BCH, k = c - r * BCH;
+        sact[p] = (r < nrows) & (k < C);
+        goff[p] = mad24_s((uint32_t)r, pitch, mul24_12((uint32_t)k));
+        wl[p] = (uint32_t)r * lpitch + (uint32_t)k * 16u;
+        smask[p] = __ballot(sact[p]);
+    }
+    const unsigned char* gsrc = a.src + (long long)f0 * a.src_img_stride + (size_t)((uint32_t)ymn * pitch + (uint32_t)xmn * 3u);   // uniform
+    unsigned char* gdst = a.dst + (long long)f0 * a.dst_img_stride;
+    const uint32_t doff = ((uint32_t)rr * (uint32_t)a.pitch_w + (uint32_t)c0p) * 3u;
+    typedef uint32_t u3 __attribute__((ext_vector_type(3)));
+    auto issue = [&](const unsigned char* gb, u3 (&v)[SLOTS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < SLOTS; ++p) {
+            unsigned long long keep;
+            asm volatile("s_mov_b64 %1, exec\n\ts_mov_b64 exec, %4\n\tglobal_load_dwordx3 %0, %2, %3\n\ts_mov_b64 exec, %1"
+                         : "=&v"(v[p]), "=&s"(keep) : "v"(goff[p]), "s"(gb), "s"(smask[p]) : "memory");
+        }
+    };
+    auto landed = [&](u3 (&v)[SLOTS]) __attribute__((always_inline)) {
+        static_assert(SLOTS == 4, "operand list below");
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : : "memory");
+    };
+    auto expand = [&](const u3 (&v)[SLOTS]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int p = 0; p < SLOTS; ++p)
+            if (sact[p]) {
+                uint4 t4;
+                t4.x = v[p].x & 0xFFFFFFu;
+                t4.y = __builtin_amdgcn_perm(v[p].y, v[p].x, 0x0C050403u);
+                t4.z = __builtin_amdgcn_perm(v[p].z, v[p].y, 0x0C040302u);
+                t4.w = v[p].z >> 8;
+                __builtin_memcpy(__builtin_assume_aligned(slab0 + wl[p], RWH_F8M_SKEW % 16 ? 8 : 16), &t4, 16);
+            }
+    };
+
+    // ---- geometry of the lane's 8 pixels, once (fast8m_body) ---------------------------------------------------------------
+    const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2);   // uniform; the block slab starts at LDS offset of slab0
+    float wa[F8_PX], wb[F8_PX], wc[F8_PX], wd[F8_PX];
+    uint32_t lo[F8_PX];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        double X[3], Y[3], W[3], rc[3];
+        uint32_t lx[FP_PX], ly[FP_PX], hx[FP_PX], hy[FP_PX];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) { X[j] = X0 + co.dxs8[3 * h + j][0]; Y[j] = Y0 + co.dxs8[3 * h + j][1]; W[j] = W0 + co.dxs8[3 * h + j][2]; }
+        const double p12 = W[0] * W[1], P = p12 * W[2];
+        double rp = __builtin_amdgcn_rcp(P);
+        rp = fma(fma(-P, rp, 1.0), rp, rp);
+        const double r12 = rp * W[2];
+        rc[2] = rp * p12; rc[0] = r12 * W[1]; rc[1] = r12 * W[0];
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const double ux = fma(X[j], rc[j], MAGIC), uy = fma(Y[j], rc[j], MAGIC);
+            const int q = j + 1 - h;
+            hx[q] = hi32(ux); lx[q] = lo32(ux); hy[q] = hi32(uy); ly[q] = lo32(uy);
+        }
+        hx[3 * h] = ehx[h]; lx[3 * h] = elx[h]; hy[3 * h] = ehy[h]; ly[3 * h] = ely[h];
+#pragma unroll
+        for (int j = 0; j < FP_PX; ++j) {
+            const int p = 4 * h + j;
+            const float wx1 = (float)lx[j], wy1 = (float)ly[j] * WS;
+            const float w11 = wx1 * wy1;
+            const float w01 = __builtin_fmaf(wx1, WO, -w11);
+            const float w10 = __builtin_fmaf(wy1, 4294967296.0f, -w11);
+            const float w00 = __builtin_fmaf(-wx1, WO, WC) - w10;
+            wa[p] = w00; wb[p] = w01; wc[p] = w10; wd[p] = w11;
+            lo[p] = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
+        }
+    }
+    u3 v[SLOTS];
+    issue(gsrc, v);
+    landed(v);
+    expand(v);
+    lds_barrier();                                             // the slab holds frame f0
+    if (f0 + 1 < f1) issue(gsrc + a.src_img_stride, v);
+    for (int f = f0; f < f1; ++f) {
+        gsrc += a.src_img_stride;
+        const bool more = f + 1 < f1;                         // block-uniform
+        pk3 w[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            float o[FP_PX][3];
+#pragma unroll
+            for (int j = 0; j < FP_PX; ++j) {
+                const int p = 4 * h + j;
+                const uint32_t* t0 = reinterpret_cast<const uint32_t*>(slab0 + lo[p]);
+                const uint32_t* t1 = reinterpret_cast<const uint32_t*>(slab0 + lo[p] + lpitch);
+                const uint32_t a0 = t0[0], b0 = t0[1], a1 = t1[0], b1 = t1[1];
+                const float w00 = wa[p], w01 = wb[p], w10 = wc[p], w11 = wd[p];
+                const uint32_t g00 = rg_halves(a0), g01 = rg_halves(b0), g10 = rg_halves(a1), g11 = rg_halves(b1);
+                o[j][0] = fmix_lo(g11, w11, fmix_lo(g10, w10, fmix_lo(g01, w01, fmix_lo_c(g00, w00, U8_BIAS))));
+                o[j][1] = fmix_hi(g11, w11, fmix_hi(g10, w10, fmix_hi(g01, w01, fmix_hi_c(g00, w00, U8_BIAS))));
+                o[j][2] = fmix_hi(b1, w11, fmix_hi(a1, w10, fmix_hi(b0, w01, fmix_hi_c(a0, w00, U8_BIAS))));
+            }
+            w[h] = pack_run_u8(o);
+        }
+        if (more) {
+            lds_barrier();                                     // every wave has taken its taps of frame f: the slab is free
+            landed(v);
+            expand(v);
+            lds_barrier();                                     // the slab holds frame f + 1
+        }
+        unsigned char* drow = gdst + doff;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int first = tshift - (lcol + (PW / 2) * h);
+            store_run_pk(w[h], drow + 3 * (PW / 2) * h, store_any & (first <= 3), max(first, 0));
+        }
+        gdst += a.dst_img_stride;
+        if (f + 2 < f1) issue(gsrc + a.src_img_stride, v);
+    }
+}
+template <int LOG_PW>
+__global__ __launch_bounds__(256, 4) void warp_rgb8_fast8mb(const FastArgs a) { fast8mb_body<LOG_PW>(a); }
+
 #ifndef RWH_F8M_WAVES
 #define RWH_F8M_WAVES 4
 #endif
 template <int LOG_PW>
 __global__ __launch_bounds__(256, RWH_F8M_WAVES) void warp_rgb8_fast8m(const FastArgs a) { fast8m_body<LOG_PW>(a); }
+
+// ---- a thin ragged right edge (round 4) -----------------------------------------------------------------------------------
+// An output row of 1921 pixels (a 1080p frame's auto-bounds grid) is 15 tiles of 128 columns and ONE column: the tile that is
+// moved left to cover it recomputes 127 columns it does not own -- 4.6 % of the 512 x 1080p batch (profiles/r03_lab_notes.txt
+// section 13).  When 1 <= out_w mod 128 <= STRIP_MAX the tiled launch covers the multiple of 128 and this kernel the rest: one
+// lane = one output ROW, all its strip pixels; coordinates, validity, weights and the fused multiply-add chain of the blend as in the
+// tiled kernels (per pixel, not per run: the strip is 0.05-0.8 % of a frame), byte-exact clamped taps.  Which columns are strip
+// columns depends on out_w only, so whole launches, row shards, batches and per-image tables still agree bit for bit.
+#ifndef RWH_STRIP_MAX
+#define RWH_STRIP_MAX 16      // (lab builds: 0 switches the strip off)
+#endif
+constexpr int STRIP_MAX = RWH_STRIP_MAX;
+template <typename DstT>
+__device__ __forceinline__ void strip_body(const FastArgs& a, const Coef* tab) {
+    constexpr bool U8 = sizeof(DstT) == 1;
+    constexpr float WS = W_SCALE * MIX_S, WO = W_ONE * MIX_S, WC = MIX_S, BIAS = U8 ? U8_BIAS : 0.f;
+    const int rr = (int)(blockIdx.x * 256 + threadIdx.x);
+    const unsigned img = blockIdx.y;
+    if (rr >= a.rows) return;
+    const Coef& co = tab ? tab[img] : a.c;
+    const unsigned img_mem = tab ? (unsigned)co.image : img;
+    const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;
+    DstT* drow = reinterpret_cast<DstT*>(a.dst + (long long)img_mem * a.dst_img_stride) + ((size_t)rr * (size_t)a.pitch_w) * 3;
+    const uint32_t pitch = (uint32_t)a.src_w * 3u, last = (uint32_t)a.src_h * pitch - 3u;
+    const double fr = (double)(a.row_begin + rr);
+    for (int c = a.out_w; c < a.pitch_w; ++c) {
+        const double fc = (double)c;
+        const double X = fma(fc, co.cx[2], fma(fr, co.cx[1], co.cx[0]));
+        const double Y = fma(fc, co.cy[2], fma(fr, co.cy[1], co.cy[0]));
+        const double W = fma(fc, co.cw[2], fma(fr, co.cw[1], co.cw[0]));
+        double r = __builtin_amdgcn_rcp(W);
+        r = fma(fma(-W, r, 1.0), r, r);
+        const double ux = fma(X, r, MAGIC), uy = fma(Y, r, MAGIC);
+        const unsigned long long ubx = (unsigned long long)__double_as_longlong(ux), uby = (unsigned long long)__double_as_longlong(uy);
+        const bool valid = (ubx >= MAGIC_BITS) & (ubx <= a.xmax_bits) & (uby >= MAGIC_BITS) & (uby <= a.ymax_bits);
+        float o[3] = {BIAS, BIAS, BIAS};
+        if (valid) {
+            const int ix = (int)(hi32(ux) - MAGIC_HI), iy = (int)(hi32(uy) - MAGIC_HI);
+            const float wx1 = (float)lo32(ux), wy1 = (float)lo32(uy) * WS;
+            const float w11 = wx1 * wy1;                                   // blend4<FOLDED>'s derivation
+            const float w01 = __builtin_fmaf(wx1, WO, -w11);
+            const float w10 = __builtin_fmaf(wy1, 4294967296.0f, -w11);
+            const float w00 = __builtin_fmaf(-wx1, WO, WC) - w10;
+            const uint32_t o00 = (uint32_t)iy * pitch + (uint32_t)ix * 3u;
+            const uint32_t o01 = min(o00 + 3u, last), o10 = min(o00 + pitch, last), o11 = min(o00 + pitch + 3u, last);   // (weight 0 when clamped)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                // a byte as the float16 denormal b * 2^-24 times a weight that carries the 2^24: the tiled kernels' v_fma_mix_f32 terms
+                const float p00 = (float)simg[o00 + k] * 0x1p-24f, p01 = (float)simg[o01 + k] * 0x1p-24f;
+                const float p10 = (float)simg[o10 + k] * 0x1p-24f, p11 = (float)simg[o11 + k] * 0x1p-24f;
+                o[k] = __builtin_fmaf(p11, w11, __builtin_fmaf(p10, w10, __builtin_fmaf(p01, w01, __builtin_fmaf(p00, w00, BIAS))));
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            if constexpr (U8) drow[3 * c + k] = (unsigned char)__builtin_amdgcn_cvt_pk_u8_f32(o[k], 0, 0);
+            else drow[3 * c + k] = o[k];
+        }
+    }
+}
+template <typename DstT>
+__global__ __launch_bounds__(256) void warp_rgb8_strip(const FastArgs a) { strip_body<DstT>(a, nullptr); }
+template <typename DstT>
+__global__ __launch_bounds__(256) void warp_rgb8_strip_tab(const FastArgs a, const CoefTab t) { strip_body<DstT>(a, t.e); }
 
 // ---- nearest neighbour, RGB u8 (homography.py:108-121), bit-exact ---------------------------------------------------
 // Same tiling, patch shapes, footprint staging and store layout as warp_rgb8_fast8; one LDS read per pixel, no blend.
@@ -1617,7 +1903,7 @@ __device__ __forceinline__ void nn_body(const FastArgs& a, const Coef* tab) {
     const int lcol = wave_x + pq * 4, c0p = tcol + lcol;
     const bool store_any = rr_raw < a.rows;
     const unsigned char* simg = a.src + (long long)img_mem * a.src_img_stride;
-    unsigned char* drow = a.dst + (long long)img_mem * a.dst_img_stride + ((uint32_t)rr * (uint32_t)a.out_w + (uint32_t)c0p) * 3u;
+    unsigned char* drow = a.dst + (long long)img_mem * a.dst_img_stride + ((uint32_t)rr * (uint32_t)a.pitch_w + (uint32_t)c0p) * 3u;
     const uint32_t pitch = (uint32_t)a.src_w * 3u;
     const int out_row = a.row_begin + rr;
 

@@ -1263,9 +1263,9 @@ def test_warp_multi_frame_equals_single(gpu, case, shape):
     _force_frames(0)
     ref = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8)
     assert "fast8<" in kernels.warp_plan(tuple(src.shape), torch.uint8, inv, grid, (333, 517), "bilinear", torch.uint8)
-    for n in (2, 3, 4, 7, 16):
+    for n in (2, 3, 4, 7, 16, 102, 103, 104, 107, 116):      # 100 + n: the variant with ONE staging window per block (warp_rgb8_fast8mb)
         _force_frames(n)
-        assert "fast8m" in kernels.warp_plan(tuple(src.shape), torch.uint8, inv, grid, (333, 517), "bilinear", torch.uint8)
+        assert ("fast8mb" if n > 100 else "fast8m<") in kernels.warp_plan(tuple(src.shape), torch.uint8, inv, grid, (333, 517), "bilinear", torch.uint8)
         got = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8)
         assert torch.equal(got, ref), (case, shape, n, int((got != ref).sum()))
         part = kernels.warp_backward(src, inv, grid, (333, 517), "bilinear", torch.uint8, rows=(100, 229))
