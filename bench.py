@@ -553,6 +553,21 @@ def profile_facts(kernel, frames, src_wh, kernel_ms, sclk_mhz=None):
     return out
 
 
+def pmc_row(kernel):
+    """The committed counter row (PMC_JSON, `other_kernels`: rocprofv3 --pmc passes of this command) of a kernel that is not the
+    headline one: which unit is busiest, i.e. what limits it (round-3 verdict item 3)."""
+    path = os.path.join(ROOT, PMC_JSON)
+    if not os.path.exists(path) or not kernel:
+        return {}
+    for key, row in json.load(open(path)).get("other_kernels", {}).items():
+        if key.startswith(kernel + "(") or key.startswith(kernel + " |"):
+            return {"pmc": {"valu_busy": row.get("valu_busy_frac"), "l2_busy": row.get("tcc_busy_frac"), "ta_busy": row.get("ta_busy_frac"),
+                            "lds_busy": row.get("lds_busy_frac"), "l1_waiting_for_l2": row.get("tcp_pending_stall_frac"),
+                            "hbm_bytes_per_launch": row.get("hbm_bytes_per_launch"), "l2_write_requests": row.get("l2_write_requests"),
+                            "limiter": row.get("limiter"), "source": PMC_JSON}}
+    return {}
+
+
 def _other_kernels_leg(backend, src_w, src_h, nb):
     torch, k = backend.torch, backend.kernels
     step, out_h, out_w, _, _, (src, _, grid, inv) = backend.make_warp(nb, src_w, src_h, 99)
@@ -570,22 +585,26 @@ def _other_kernels_leg(backend, src_w, src_h, nb):
         if hasattr(backend, "load_facts"):      # what limits it: the clock the chip holds and the board power under this kernel
             other[name].update(backend.load_facts(step2, 0.7))
         del d2
-    # minification 1.5x (scanner mode shrinks A4 scans): a 64 x 8 patch's footprint (98 x 14 texels) no longer fits a 5 KB
-    # window, and at s^2 = 2.25 staged texels per output pixel against 4 taps used staging stops paying: masked gathers
-    zin = np.array([[1.5, 0.0, 0.0], [0.0, 1.5, 0.0], [0.0, 0.0, 1.0]])       # inv(H): output pixel -> source texel
-    zw, zh = int(src_w / 1.5), int(src_h / 1.5)
-    zgrid = k.Grid(0, zw - 1, zw, 0, zh - 1, zh)
-    dz = torch.empty((nb, zh, zw, 3), dtype=torch.uint8, device=backend.dev)
+    # minification (scanner mode shrinks A4 scans).  1.5x: a 64 x 8 patch's footprint (98 x 14 texels) no longer fits a 5 KB window, the
+    # patch is staged by halves; 2.5x: s^2 = 6.25 staged texels per output pixel against 4 taps used -- staging stops paying at ~1.8x,
+    # masked gathers (whose cost per OUTPUT pixel does not depend on s, while the roofline's bytes per output pixel grow as s^2)
+    for zname, zs, zpath in (("zoom_out_1p5", 1.5, "staged by half patches (16-wide halves fit the window up to ~1.8x)"),
+                             ("zoom_out_2p5", 2.5, "masked gathers (a staged window would hold 6.25 texels per output pixel for the 4 it uses)")):
+        zin = np.array([[zs, 0.0, 0.0], [0.0, zs, 0.0], [0.0, 0.0, 1.0]])       # inv(H): output pixel -> source texel
+        zw, zh = int(src_w / zs), int(src_h / zs)
+        zgrid = k.Grid(0, zw - 1, zw, 0, zh - 1, zh)
+        dz = torch.empty((nb, zh, zw, 3), dtype=torch.uint8, device=backend.dev)
 
-    def stepz():
-        k.warp_backward(src, zin, zgrid, (src_h, src_w), "bilinear", torch.uint8, zero_origin=False, out=dz)
-    _, ms = timed(backend, stepz, 20, 20, backend.sync, PREWARM_MS)
-    byt = nb * 3 * (src_h * src_w + zh * zw)
-    other["zoom_out_1p5"] = {"kernel": k.warp_plan((nb, src_h, src_w, 3), torch.uint8, zin, zgrid, (src_h, src_w), "bilinear", torch.uint8),
-                             "path": "staged by half patches (round 3: 16-wide halves fit the window up to ~1.8x; beyond, gathers)",
-                             "mpix_per_s": round(nb * zh * zw / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "frames": nb,
-                             "achieved_GBps": round(byt / ms / 1e6, 1), "frac_of_hbm_peak": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
-    del dz
+        def stepz():
+            k.warp_backward(src, zin, zgrid, (src_h, src_w), "bilinear", torch.uint8, zero_origin=False, out=dz)
+        _, ms = timed(backend, stepz, 20, 20, backend.sync, PREWARM_MS)
+        byt = nb * 3 * (src_h * src_w + zh * zw)
+        other[zname] = {"kernel": k.warp_plan((nb, src_h, src_w, 3), torch.uint8, zin, zgrid, (src_h, src_w), "bilinear", torch.uint8),
+                        "path": zpath, "mpix_per_s": round(nb * zh * zw / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "frames": nb,
+                        "achieved_GBps": round(byt / ms / 1e6, 1), "frac_of_hbm_peak": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
+        if hasattr(backend, "load_facts"):
+            other[zname].update(backend.load_facts(stepz, 0.5))
+        del dz
     # 4-channel images (the reference's RGBA = float32 with the alpha plane of addAlpha; uint8 RGBA for completeness): the
     # generic gather kernel -- 16-byte float32 texels gather well, there is no staged kernel for them
     nb4 = min(nb, 8)
@@ -601,6 +620,8 @@ def _other_kernels_leg(backend, src_w, src_h, nb):
                        "mpix_per_s": round(nb4 * out_h * out_w / ms / 1e3, 1), "ms_per_launch": round(ms, 4), "frames": nb4,
                        "achieved_GBps": round(byt / ms / 1e6, 1), "frac_of_hbm_peak": round(byt / ms / 1e6 / HBM_PEAK_GBS, 4)}
         del s4, d4
+    for row in other.values():
+        row.update(pmc_row(row.get("kernel")))
     return other
 
 

@@ -15,6 +15,10 @@
 #include <climits>
 #include <cstring>
 #include <vector>
+#ifdef RWH_RUN_STAMPS
+#include <chrono>
+#include <cstdio>
+#endif
 #include "rwh_common.h"
 
 namespace {
@@ -60,6 +64,21 @@ void layout(int m, int k, long long* off) {
     off[H_END] = (long long)h;
 }
 
+#ifdef RWH_RUN_STAMPS       // lab build: where the host time of one call goes (stderr)
+struct Stamps {
+    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now(), last = t0;
+    void at(const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[run] %-28s +%7.1f us  (%7.1f)\n", what, std::chrono::duration<double, std::micro>(now - last).count(),
+                std::chrono::duration<double, std::micro>(now - t0).count());
+        last = now;
+    }
+};
+#define STAMP(w) stamps.at(w)
+#else
+#define STAMP(w) ((void)0)
+#endif
+
 inline int margin_of(int best, int cap) { const int v = 3 + (best > 0 ? best : 0) / 16; return v < cap ? v : cap; }
 }  // namespace
 
@@ -88,6 +107,10 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
     for (long long i = 0; i < 4ll * k; ++i)
         if (idx[i] < 0 || idx[i] >= m) return RWH_E_INVALID;
     hipStream_t s = static_cast<hipStream_t>(stream);
+#ifdef RWH_RUN_STAMPS
+    Stamps stamps;
+#endif
+    STAMP("validate idx");
     long long off[N_OFF];
     layout(m, k, off);
     unsigned char* D = static_cast<unsigned char*>(d_ws);
@@ -137,9 +160,14 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
     int st = rwh_ransac_search(d_pa, d_pb, m, d_idx, k, th, loss, need, 0, d_H, d_flags, d_counts, d_masks, d_best, 1, s);
     if (st != RWH_OK) return st;
     if (hipMemcpyAsync(h_counts, d_counts, 5 * (size_t)k, hipMemcpyDeviceToHost, s) != hipSuccess) return RWH_E_LAUNCH;   // counts + flags
+    STAMP("staging copy + enqueue");
 
     // ---- hypotheses settled so far: position in the Hset / cnt_set / mask_set tables, -1 = not settled -------------------
-    std::vector<int> pos((size_t)k, -1), cnt((size_t)k, 0);
+    // (per-thread scratch that keeps its pages between calls: four fresh 400 KB vectors per call at k = 100 000 cost ~0.15 ms of page faults)
+    static thread_local std::vector<int> pos_tl, cnt_tl, lo_tl, hi_tl, act_tl;
+    std::vector<int>&pos = pos_tl, &cnt = cnt_tl, &lo = lo_tl, &hi = hi_tl, &act = act_tl;
+    pos.assign((size_t)k, -1);
+    cnt.resize((size_t)k);
     int nset = 0, rounds = 0;
     auto settle = [&](int n_rows) -> int {      // h_rows[0..n_rows) -> H by the reference's solver, counts + masks by K2
         if (n_rows == 0) return RWH_OK;
@@ -170,29 +198,39 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
         const int32_t* q = idx + 4 * (size_t)i;
         if ((q[0] == q[1]) | (q[0] == q[2]) | (q[0] == q[3]) | (q[1] == q[2]) | (q[1] == q[3]) | (q[2] == q[3])) h_rows[n_rep++] = i;
     }
+    STAMP("vectors + repeated scan");
     st = settle(n_rep);
     if (st != RWH_OK) { (void)hipStreamSynchronize(s); return st; }
+    STAMP("repeated-index SVDs");
     if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
-    for (int i = 0; i < k; ++i) cnt[(size_t)i] = h_counts[i];
+    STAMP("sync 1");
+    memcpy(cnt.data(), h_counts, 4 * (size_t)k);
     absorb(n_rep);
     int n_flagged = 0;
     for (int i = 0; i < k; ++i) n_flagged += h_flags[i] != 0;
 
+    STAMP("counts copy + flag count");
     // ---- 'fwd': count intervals for the candidates (see the comment above the function) ------------------------------------
     double cscale = 1.0;
     for (long long i = 0; i < 2ll * m; ++i) { const double v = pts_a[i] < 0 ? -(double)pts_a[i] : (double)pts_a[i]; if (v > cscale) cscale = v; }
     const bool use_iv = loss == RWH_LOSS_FWD && cscale < 1e30;            // (an Inf / NaN coordinate: the margin rule)
     const unsigned always_bits = use_iv ? (RWH_HYP_REPEATED | RWH_HYP_SINGULAR | RWH_HYP_DEGENERATE) : 0xFFu;
-    std::vector<int> lo, hi;
     int n_iv = 0;
     if (use_iv) {
-        lo.assign(cnt.begin(), cnt.end()); hi = lo;                        // not a candidate: its count is taken as it is
+        lo.resize((size_t)k); hi.resize((size_t)k);
+        memcpy(lo.data(), cnt.data(), 4 * (size_t)k);                      // not a candidate: its count is taken as it is
+        memcpy(hi.data(), cnt.data(), 4 * (size_t)k);
         int best0 = 0;
-        for (int i = 0; i < k; ++i)
-            if (!(h_flags[i] & always_bits) && cnt[(size_t)i] > best0) best0 = cnt[(size_t)i];
-        for (int i = 0; i < k; ++i)
-            if (pos[(size_t)i] < 0 && !(h_flags[i] & always_bits) &&
-                ((h_flags[i] & RWH_HYP_ILLCOND) || cnt[(size_t)i] >= best0 - IV_NEAR || cnt[(size_t)i] >= need - IV_NEAR)) h_rows[n_iv++] = i;
+        for (int i = 0; i < k; ++i) {
+            const int c = (h_flags[i] & always_bits) ? 0 : cnt[(size_t)i];
+            best0 = c > best0 ? c : best0;
+        }
+        const int near_lim = (best0 < need ? best0 : need) - IV_NEAR;      // cnt >= best0 - NEAR or cnt >= need - NEAR
+        for (int i = 0; i < k; ++i) {
+            const unsigned f = h_flags[i];
+            if (!(f & always_bits) && ((f & RWH_HYP_ILLCOND) || cnt[(size_t)i] >= near_lim) && pos[(size_t)i] < 0) h_rows[n_iv++] = i;
+        }
+        STAMP("lo/hi init + candidates");
         if (n_iv) {
             if (hipMemcpyAsync(d_rows, h_rows, 4 * (size_t)n_iv, hipMemcpyHostToDevice, s) != hipSuccess) return RWH_E_LAUNCH;
             st = rwh_score_interval(d_H, d_rows, n_iv, d_flags, d_pa, d_pb, m, th, cscale, IV_DELTA0, IV_DELTA1, d_lo, d_hi, s);
@@ -205,8 +243,56 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
         }
     }
 
+    STAMP("interval kernel round trip");
     // ---- rounds: settle every hypothesis that can take part in the decision (ransac._settle_on_host, same rules) ----------
     int end = k;
+    if (use_iv) {
+        // The same rules as the general loop below, without three passes over all k hypotheses per round.  Only a hypothesis that is
+        // not settled and either carries an always-bit or has an open interval (lo < hi) can ever be taken: the ACTIVE list, a few
+        // thousand of 100 000.  Every other one is fixed for the whole call: v[] = what it contributes to the running best (lo; 0 for
+        // an unsettled always-bit sample; the settled count once settled -- kept in lo[]), `fs` = the first hypothesis that
+        // certainly exits.
+        act.clear();
+        int fs = k;
+        for (int i = k - 1; i >= 0; --i) {
+            const bool settled = pos[(size_t)i] >= 0, always = (h_flags[i] & always_bits) != 0;
+            int v;
+            if (settled) v = cnt[(size_t)i];
+            else if (always) v = 0;
+            else v = lo[(size_t)i];
+            if ((settled || !always) && v >= need) fs = i;
+            if (!settled && (always || lo[(size_t)i] < hi[(size_t)i])) act.push_back(i);
+            lo[(size_t)i] = v;                                  // from here on lo[] is v[]
+        }
+        std::reverse(act.begin(), act.end());                   // ascending, like the general loop's h_rows
+        for (;;) {
+            end = fs < k ? fs + 1 : k;
+            int best = 0;
+            for (int i = 0; i < end; ++i) best = lo[(size_t)i] > best ? lo[(size_t)i] : best;
+            int n_rows = 0;
+            size_t keep = 0;
+            for (size_t a = 0; a < act.size(); ++a) {
+                const int i = act[a];
+                const bool take = i < end && ((h_flags[i] & always_bits) || hi[(size_t)i] >= best || hi[(size_t)i] >= need);
+                if (take) h_rows[n_rows++] = i; else act[keep++] = i;
+            }
+            act.resize(keep);
+            STAMP("round scans");
+            if (n_rows == 0) break;
+            ++rounds;
+            st = settle(n_rows);
+            if (st != RWH_OK) { (void)hipStreamSynchronize(s); return st; }
+            if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
+            const int first_new = nset;
+            absorb(n_rows);
+            for (int j = 0; j < n_rows; ++j) {
+                const int i = h_rows[j], c = h_cntset[first_new + j];
+                lo[(size_t)i] = c;
+                if (c >= need && i < fs) fs = i;
+            }
+            STAMP("round settle + sync");
+        }
+    } else
     for (;;) {
         end = k;
         const int m_need = margin_of(need, margin_cap);
@@ -234,12 +320,14 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
             else take = h_flags[i] != 0 || cnt[(size_t)i] >= best - m_best || cnt[(size_t)i] >= need - m_need;
             if (take) h_rows[n_rows++] = i;
         }
+        STAMP("round scans");
         if (n_rows == 0) break;
         ++rounds;
         st = settle(n_rows);
         if (st != RWH_OK) { (void)hipStreamSynchronize(s); return st; }
         if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
         absorb(n_rows);
+        STAMP("round settle + sync");
     }
 
     // ---- the accept rules (ransac.py:186-202) over the prefix the reference looks at ------------------------------------
@@ -266,7 +354,9 @@ extern "C" int rwh_ransac_run(const float* pts_a, const float* pts_b, int m, con
         if (hipStreamSynchronize(s) != hipSuccess) return RWH_E_LAUNCH;
         for (int w = 0; w < words; ++w) out_mask[w] = h_mask[w];
     }
+    STAMP("accept rules + mask readback");
     // for the caller's diagnostics: the settled counts replace K2's in the host copy (the device copy keeps K2's own)
     for (int i = 0; i < k; ++i) h_cntset[i] = cnt[(size_t)i];      // (h_cntset is free again: every batch has been absorbed)
+    STAMP("settled counts out");
     return RWH_OK;
 }

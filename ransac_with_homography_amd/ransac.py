@@ -130,7 +130,22 @@ def legacy_randint_table(m, k, n, want64=True):
     return t, np.ascontiguousarray(t, dtype=np.int32)
 
 
-HOST_THREADS = max(1, min(16, (os.cpu_count() or 1)))
+def _host_thread_share():
+    """Host threads of the settle step's LAPACK loop: this process's share of the cores it may run on -- one rank per GPU under
+    torchrun (LOCAL_WORLD_SIZE), so 8 ranks on a 256-thread host take 32 each -- capped at 32 (k = 100 000 on matchespoints: 3 257
+    repeated-index SVDs take 1.0 ms on 16 threads, 0.55 ms on 32, 0.44 ms on 64: tools/run_phases.py)."""
+    try:
+        cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        cpus = os.cpu_count() or 1
+    try:
+        ranks = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))
+    except ValueError:
+        ranks = 1
+    return max(1, min(32, cpus // ranks))
+
+
+HOST_THREADS = _host_thread_share()
 FORCE_PYTHON_DRIVER = False        # tests: RANSAC.run through the Python twin of rwh_ransac_run
 
 

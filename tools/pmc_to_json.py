@@ -14,6 +14,8 @@ def facts(name, grid):
     c = summ["%s|%d" % (name, grid)]
     cyc = c["SQ_BUSY_CYCLES"] / 32                      # 32 shader engines
     us = kernel_us(name, grid)
+    if us != us:
+        raise KeyError("no launch of this kernel / grid in the trace of pass 1")
     e = {"waves_per_launch": round(c["SQ_WAVES"]), "valu_insts_per_wave": round(c["SQ_INSTS_VALU"] / c["SQ_WAVES"], 1),
          "salu_insts_per_wave": round(c["SQ_INSTS_SALU"] / c["SQ_WAVES"], 1), "kernel_cycles": round(cyc), "sclk_hz": round(cyc / (us * 1e-6)),
          "kernel_us_in_pmc_pass": round(us, 1), "valu_busy_frac": round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / cyc, 3),
@@ -37,10 +39,10 @@ for key, grid, src, frames, alg in (("rwh::warp_rgb8_fast8<unsigned char, 6>", 3
     e = {"src": src, "frames": frames}
     e.update(facts(KERNEL, grid))
     e["algorithmic_bytes_per_launch"] = alg
-    e["limiter"] = ("VALU busy %d %% (%d VALU instructions per 512-pixel wave at %.2f cycles each), L2 busy %d %%, texture-address path busy %d %%, LDS busy %d %% "
+    e["limiter"] = ("VALU busy %d %% (%d VALU instructions per 512-pixel wave at %.2f cycles each), L1s waiting on L2 / HBM %d %% of the cycles, texture-address path busy %d %%, LDS busy %d %% "
                     "(%d %% of it bank conflicts); HBM traffic = %.4f x algorithmic; the access pattern alone (tools/pattern_probe.hip) takes 0.31 ms per 32 x 4K: "
                     "arithmetic and memory are near-equal and overlap imperfectly" %
-                    (100 * e["valu_busy_frac"], e["valu_insts_per_wave"], e["cycles_per_valu_inst"], 100 * e.get("tcc_busy_frac", 0), 100 * e["ta_busy_frac"],
+                    (100 * e["valu_busy_frac"], e["valu_insts_per_wave"], e["cycles_per_valu_inst"], 100 * e.get("tcp_pending_stall_frac", 0), 100 * e["ta_busy_frac"],
                      100 * e["lds_busy_frac"], 100 * e["lds_bank_conflict_share"], e["hbm_bytes_per_launch"] / alg))
     doc[key] = e
 others = {}
@@ -52,11 +54,20 @@ for k in sorted(summ):
         continue
     try:
         f = facts(name, int(grid))
-    except (KeyError, ZeroDivisionError):
+    except (KeyError, ZeroDivisionError, ValueError):
         continue
-    busy = {"VALU": f["valu_busy_frac"], "L2": f.get("tcc_busy_frac", 0), "texture-address path": f["ta_busy_frac"], "LDS": f["lds_busy_frac"]}
+    # TCC_BUSY counts cycles with ANY request pending (~100 % for every streaming kernel): not a throughput figure.  What tells a
+    # memory-bound kernel apart is how long the CUs' L1s sit on outstanding L2 / HBM requests, and the HBM rate it reaches
+    # (a plain copy of read + write bytes gets 4.7-4.9 TB/s from this memory system: profiles/r04_lab_notes.txt section 5)
+    busy = {"VALU": f["valu_busy_frac"], "texture-address path": f["ta_busy_frac"], "LDS": f["lds_busy_frac"]}
     top = sorted(busy.items(), key=lambda kv: -kv[1])
-    f["limiter"] = "busiest units: " + ", ".join("%s %d %%" % (n, 100 * v) for n, v in top[:3])
+    f["hbm_TBps_in_pmc_pass"] = round(f["hbm_bytes_per_launch"] / f["kernel_us_in_pmc_pass"] / 1e6, 2)
+    f["l2_requests_per_channel_clock"] = round(f.get("tcc_requests", 0) / 128.0 / f["kernel_cycles"], 3)
+    f["limiter"] = ("%s: HBM traffic %.2f TB/s (a plain copy: 4.7-4.9), L1s waiting on outstanding L2 / HBM requests %d %% of the cycles, "
+                    "L2 request rate %.2f per channel-clock; execution units: %s" %
+                    ("memory system" if f.get("tcp_pending_stall_frac", 0) > 0.6 and top[0][1] < 0.95 else "%s and the memory system" % top[0][0],
+                     f["hbm_TBps_in_pmc_pass"], 100 * f.get("tcp_pending_stall_frac", 0), f["l2_requests_per_channel_clock"],
+                     ", ".join("%s %d %%" % (n, 100 * v) for n, v in top)))
     others["%s | grid %s" % (name.replace("void ", ""), grid)] = f
 doc["other_kernels"] = others
 json.dump(doc, open(out, "w"), indent=0)
