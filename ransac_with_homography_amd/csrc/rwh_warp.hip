@@ -446,8 +446,8 @@ static int choose_shape(const FastArgs& a, int r0 = 0, int c0 = 0, int nr = -1, 
                         const double r = r0 + (nr > ph ? (nr - ph) * (i / 4.0) : 0.0), c = c0 + (nc > pw ? (nc - pw) * (j / 4.0) : 0.0);
                         long long fr, ft; double ln;
                         if (!patch_footprint(a, __builtin_floor(r), __builtin_floor(c) + h * (pw / 2), pw / 2, ph, &fr, &ft, &ln)) continue;
-                        ++seen; fit += f8_window_fits(lp, fr, ft + 3);      // + 3: the window starts on a multiple of 4 texels
-                        staged += (double)fr * (double)(((ft + 6) >> 2) << 2);
+                        ++seen; fit += f8_window_fits(lp, fr, ft);          // (ft counts from the window's start, a multiple of 4 texels)
+                        staged += (double)fr * (double)(((ft + 3) >> 2) << 2);
                     }
             if (seen && 10 * fit >= 9 * seen && staged <= HALVES_MAX_TEXELS * 256.0 * seen) return lp + 8;
         }

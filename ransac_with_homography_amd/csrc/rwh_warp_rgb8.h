@@ -180,6 +180,30 @@ __device__ __forceinline__ float fmix_hi_c(uint32_t h, float w, float acc_unifor
 // RGBX texel (X == 0) -> R | G << 16
 __device__ __forceinline__ uint32_t rg_halves(uint32_t t) { return __builtin_amdgcn_perm(0u, t, 0x0C010C00u); }
 
+// float32 output, whole-run stores (uniform: no lane of the wave straddles a ragged row): a run's 4 * PSTR pixels per lane group --
+// pixel j of lane l is column l + j * PSTR of the group's row segment -- are re-dealt through `region` (48 * PSTR bytes of LDS per group)
+// so that lane l stores the 16-byte pieces l, PSTR + l, 2 * PSTR + l of the contiguous 48 * PSTR-byte segment: three fully coalesced
+// dwordx4 stores instead of four 12-byte ones (the texture-address path charges a dwordx3 like a dwordx4 and dislikes strided pieces).
+template <int PSTR>
+__device__ __forceinline__ void redeal_store_f32(const float (&o)[FP_PX][3], float* drow, bool store_any, unsigned char* region, int l) {
+#pragma unroll
+    for (int j = 0; j < FP_PX; ++j) {
+        const pk3 w = {__float_as_uint(o[j][0]), __float_as_uint(o[j][1]), __float_as_uint(o[j][2])};
+        __builtin_memcpy(region + 12 * (l + j * PSTR), &w, 12);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    unsigned char* seg = reinterpret_cast<unsigned char*>(drow) - 12 * l;   // the group's row segment
+#pragma unroll
+    for (int v = 0; v < 3; ++v) {
+        const uint4 piece = *reinterpret_cast<const uint4*>(region + 16 * (v * PSTR + l));
+        if (store_any) __builtin_memcpy(seg + 16 * (v * PSTR + l), &piece, 16);
+    }
+    // the next run's pieces go to the same region: its LDS writes queue behind these reads (in-order LDS)
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <bool U8, int CH = 3, bool FOLDED = false>
 __device__ __forceinline__ void blend4(const uint32_t (&a0)[FP_PX], const uint32_t (&b0)[FP_PX],
                                        const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
@@ -229,8 +253,7 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
                                             const uint32_t (&a1)[FP_PX], const uint32_t (&b1)[FP_PX],
                                             const float (&wx0)[FP_PX], const float (&wx1)[FP_PX],
                                             const float (&wy0)[FP_PX], const float (&wy1)[FP_PX],
-                                            DstT* drow, bool store_any, int shift, unsigned char* xpose = nullptr,
-                                            int group = 0, int l = 0) {
+                                            DstT* drow, bool store_any, int shift) {
     constexpr bool U8 = sizeof(DstT) == 1;
     if constexpr (CH == 4) {                                  // RGBA uint8: a pixel is one dword, a run 16 bytes
         static_assert(U8 && PSTR == 1, "the 4-channel form is uint8 in, uint8 out");
@@ -267,33 +290,12 @@ __device__ __forceinline__ void blend_store(const uint32_t (&a0)[FP_PX], const u
     }
     float o[FP_PX][3];
     blend4<U8, 3, FOLDED>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
-    if (!store_any && !xpose) return;
+    if (!store_any) return;
 #ifdef RWH_ABL_NOSTORE  // tools/warp_lab ablation hook (never defined in the product build)
     if (o[0][0] + o[1][1] + o[2][2] + o[3][0] != -12345.f) return;
 #endif
     if constexpr (PSTR > 1) {
         static_assert(!U8, "strided runs are the float32 layout");
-        if (xpose) {                                          // uniform; the caller guarantees shift == 0 for the wave
-            unsigned char* region = xpose + group * (48 * PSTR);
-#pragma unroll
-            for (int j = 0; j < FP_PX; ++j) {
-                const pk3 w = {__float_as_uint(o[j][0]), __float_as_uint(o[j][1]), __float_as_uint(o[j][2])};
-                __builtin_memcpy(region + 12 * (l + j * PSTR), &w, 12);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            unsigned char* seg = reinterpret_cast<unsigned char*>(drow) - 12 * l;   // the group's row segment
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const uint4 piece = *reinterpret_cast<const uint4*>(region + 16 * (v * PSTR + l));
-                if (store_any) __builtin_memcpy(seg + 16 * (v * PSTR + l), &piece, 16);
-            }
-            // the next run's pieces go to the same region: its LDS writes queue behind these reads (in-order LDS)
-            __builtin_amdgcn_wave_barrier();
-            return;
-        }
-        if (!store_any) return;
 #pragma unroll
         for (int j = 0; j < FP_PX; ++j)
             if (j * PSTR >= shift) {
@@ -666,10 +668,18 @@ inline bool f8_window_fits(int log_pw, long long nrows, long long ntex) {   // h
 // of them (its 64-register / 8-wave build fitted only by spilling a dozen scalars into VGPR lanes and was 0.8 % slower); round
 // 3's v_fma_mix_f32 blend keeps no converted taps and comes to 60 VGPRs under the same bound, so 8 waves per SIMD are
 // resident after all (LDS: 8 blocks x 20 160 B per CU) -- no spills of either kind.
-// 32 x 16 patches 6 (their windows need the LDS).  float32 output (3 KB more LDS per wave for the re-deal) and the
-// compositor: LDS allows 5 (4 for 32 x 16 patches) and 6.
+// 32 x 16 patches 6 (their windows need the LDS).  The compositor: 6.  float32 output: 5 -- round 4 freed its extra 3 KB of LDS per wave
+// (the re-deal region now lies inside the staging window), so its occupancy is a choice: same-box sweeps at 4 / 5 / 6 / 7 resident waves per
+// SIMD (tools/occ_sweep_f32.sh): 0.386-0.392 ms per 16 x 4K at 4, 5 and 6, 0.406 at 7 (and 0.43 vs 0.47 in the slow allocation mode: this
+// write-heavy kernel is bound by the memory system, more streams in flight make it slower, profiles/r04_lab_notes.txt section 9).
+#ifndef RWH_LDS_PAD
+#define RWH_LDS_PAD 0
+#endif
+#ifndef RWH_F32_WAVES
+#define RWH_F32_WAVES 5
+#endif
 template <typename DstT, int LOG_PW> constexpr int f8_waves() {
-    return sizeof(DstT) == 1 ? (LOG_PW == 7 ? 7 : LOG_PW == 5 ? 6 : 7) : (LOG_PW == 5 ? 4 : 5);
+    return sizeof(DstT) == 1 ? (LOG_PW == 7 ? 7 : LOG_PW == 5 ? 6 : 7) : (LOG_PW == 5 ? (RWH_F32_WAVES < 6 ? RWH_F32_WAVES : 6) : RWH_F32_WAVES);
 }
 // Order of work inside a wave: the two END pixels of every lane (own reciprocals) give the footprint and the staging
 // loads go out at once; the other six pixels are computed run by run (3 + 3, one batch inversion each) right before
@@ -700,9 +710,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     constexpr int PW = 1 << LOG_PW, PH = 512 / PW;          // patch width / height in pixels
     constexpr int LPR = PW / 8;                             // lanes per patch row
     constexpr int WX = 128 / PW;                            // waves side by side in the block tile
-    // float32 output: 3 KB more per wave, through which a run's pixels are re-dealt into coalesced 16-byte stores (blend_store)
-    constexpr int XPOSE = sizeof(DstT) == 1 ? 0 : 3072;
-    constexpr int SLAB = F8Window<LOG_PW>::SLAB + XPOSE;
+    // (float32 output re-deals a run's pixels into coalesced 16-byte stores through the window itself once its taps are read:
+    //  redeal_store_f32; every window is larger than the 3 KB that takes)
+    constexpr int SLAB = F8Window<LOG_PW>::SLAB + RWH_LDS_PAD;     // (RWH_LDS_PAD: lab builds that lower the occupancy through the LDS budget; 0 in the product)
+    static_assert(sizeof(DstT) == 1 || SLAB >= 3072, "the re-deal region of the float32 output lies inside the staging window");
     // weight constants: RGB taps enter the blend as float16 halves (b * 2^-24), so the weights carry 2^24 (blend4)
     constexpr bool MX = CH == 3 && MIX_RGB;
     constexpr float WS = MX ? W_SCALE * MIX_S : W_SCALE, WO = MX ? W_ONE * MIX_S : W_ONE, WC = MX ? MIX_S : 1.0f;
@@ -942,8 +953,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {                           // the two runs of 4 pixels: registers are reused
+        auto taps_of_run = [&](const int h) __attribute__((always_inline)) {      // coordinates, weights and the 16 taps of run h
             run_coords(h);
 #pragma unroll
             for (int j = 0; j < FP_PX; ++j) {
@@ -957,13 +967,28 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
 #endif
             }
+        };
+        if constexpr (PSTR > 1) {
+            // float32 output, no ragged row in this tile (uniform): both runs are blended BEFORE anything is stored -- run 1 first, its
+            // 12 floats kept --, so that every tap has been read and the staging window itself can serve as the re-deal region
+            // (round 4: the 3 KB the region used to take beside the window cost three of the eight resident waves per SIMD)
+            if (tshift == 0) {
+                float o1[FP_PX][3], o0[FP_PX][3];
+                taps_of_run(1);
+                blend4<false, 3, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o1);
+                taps_of_run(0);
+                blend4<false, 3, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o0);
+                unsigned char* region = my + prow * (48 * PSTR);           // (the wave's LDS operations execute in order: these writes follow every tap read)
+                redeal_store_f32<PSTR>(o0, drow, store_any, region, pq);
+                redeal_store_f32<PSTR>(o1, drow + CH * (PW / 2), store_any, region, pq);
+                return;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                           // the two runs of 4 pixels: registers are reused
+            taps_of_run(h);
             const int first = tshift - (lcol + (PW / 2) * h);   // local pixels at columns >= first are this tile's
-            if constexpr (PSTR > 1) {
-                // float32 output: re-deal through the free upper half of the slab when there is one (uniform)
-                unsigned char* xp = tshift == 0 ? my + Win::SLAB : nullptr;
-                blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
-                                        xp ? store_any : store_any & (first <= 3 * PSTR), max(first, 0), xp, prow, pq);
-            } else if constexpr (COMP) {
+            if constexpr (COMP) {
                 float o[FP_PX][3];
                 blend4<true, 3, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, o);
                 uint32_t q[FP_PX];
@@ -1072,15 +1097,22 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     }
 
     // ---- HALVES: one run at a time, each half patch with a window of its own; halves that do not fit are left to the gathers --
+    // Round 4: BOTH halves' staging loads go out before either is waited for (round 3 staged, waited and blended half 0, then staged
+    // half 1: two exposed load latencies per wave in a kernel whose units are all below 50 % busy).  The second half's 15 chunk
+    // registers stay live across the first half's blend; its coordinates are recomputed when its turn comes (40 VALU instructions,
+    // cheaper than 16 more live registers).
     unsigned todo = 3u;                                         // uniform: runs still to do
     if constexpr (HALVES) {
         todo = wpos ? 0u : 3u;
+        if (wpos) {
+            constexpr uint32_t lpitch = Win::LPITCH;
+            chunk_t vh[2][Win::PASSES];
+            int hrows[2];                                       // uniform, per half: rows of its window (0: does not fit)
+            uint32_t tapc[2];                                   // uniform, per half: the tap-address constant of its window
+            bool hact[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            if (!wpos) break;
-            run_coords(h);
-            {
-
+            for (int h = 0; h < 2; ++h) {
+                run_coords(h);
                 const uint32_t lhx = h == 0 ? ehx[0] : hx[0], lhy = h == 0 ? ehy[0] : hy[0];      // the run's first pixel
                 const uint32_t rhx = h == 0 ? hx[3] : ehx[1], rhy = h == 0 ? hy[3] : ehy[1];      // ... and its last
                 const int hx0 = (int)__builtin_amdgcn_readlane(lhx, 0), hx1 = (int)__builtin_amdgcn_readlane(rhx, LPR - 1);
@@ -1091,55 +1123,59 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                 const int qymn = smin(smin(hy0, hy1), smin(hy2, hy3)), qymx = smax(smax(hy0, hy1), smax(hy2, hy3));
                 const int sxmn = (int)((uint32_t)smax(qxmn, 0) - MAGIC_HI), sxmx = (int)((uint32_t)smax(qxmx, 0) - MAGIC_HI);
                 const int symn = (int)((uint32_t)smax(qymn, 0) - MAGIC_HI), symx = (int)((uint32_t)smax(qymx, 0) - MAGIC_HI);
-                const int hrows = symx - symn + 2, hC = (sxmx - sxmn + 5) >> 2;
+                const int nr = symx - symn + 2, hC = (sxmx - sxmn + 5) >> 2;
                 const bool hfits = (sxmn >= 0) & (sxmx < a.bound_w - 1) & (symn >= 0) & (symx < min(a.bound_h - 1, a.src_h - 2)) &
-                                   (hrows >= Win::RPP) & (hrows <= Win::ROWS) & (hC <= Win::LPRW);
+                                   (nr >= Win::RPP) & (nr <= Win::ROWS) & (hC <= Win::LPRW);
+                hrows[h] = hfits ? nr : 0;
+                hact[h] = (srow < Win::RPP) & (scol < hC);
+                tapc[h] = ((uint32_t)qymn & 0xFFFFFFu) * lpitch + ((uint32_t)qxmn << 2) - (uint32_t)pwave * (uint32_t)SLAB;
                 if (hfits) {
-                    constexpr uint32_t lpitch = Win::LPITCH;
                     const unsigned char* gbase = simg + (size_t)((uint32_t)symn * pitch + (uint32_t)sxmn * (uint32_t)CH);   // uniform
-                    const bool hactive = (srow < Win::RPP) & (scol < hC);
-                    chunk_t vh[Win::PASSES];
 #pragma unroll
                     for (int p = 0; p < Win::PASSES; ++p)
-                        if (p * Win::RPP < hrows && hactive)
-                            __builtin_memcpy(&vh[p], gbase + (size_t)((uint32_t)min(p * Win::RPP, hrows - Win::RPP) * pitch) + goff, sizeof(chunk_t));
-#pragma unroll
-                    for (int p = 0; p < Win::PASSES; ++p)
-                        if (p * Win::RPP < hrows && hactive) {
-                            uint4 t4;
-                            if constexpr (CH == 4) {
-                                t4.x = vh[p].a; t4.y = vh[p].b; t4.z = vh[p].c; t4.w = vh[p].d;
-                            } else {
-                                t4.x = vh[p].a & 0xFFFFFFu;
-                                t4.y = __builtin_amdgcn_perm(vh[p].b, vh[p].a, 0x0C050403u);
-                                t4.z = __builtin_amdgcn_perm(vh[p].c, vh[p].b, 0x0C040302u);
-                                t4.w = vh[p].c >> 8;
-                            }
-                            *reinterpret_cast<uint4*>(my + (uint32_t)min(p * Win::RPP, hrows - Win::RPP) * lpitch + wl) = t4;
-                        }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    const uint32_t slab_off = (uint32_t)pwave * (uint32_t)SLAB;
-                    const uint32_t tap_c = ((uint32_t)qymn & 0xFFFFFFu) * lpitch + ((uint32_t)qxmn << 2) - slab_off;   // uniform
-#pragma unroll
-                    for (int j = 0; j < FP_PX; ++j) {
-                        weights2(lx[j], ly[j], WS, WO, WC, wx0[j], wx1[j], wy0[j], wy1[j]);
-                        const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tap_c));
-                        const uint32_t* t0 = reinterpret_cast<const uint32_t*>(slab0 + lo);
-                        const uint32_t* t1 = reinterpret_cast<const uint32_t*>(slab0 + lo + lpitch);
-                        a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
-                    }
-                    const int first = tshift - (lcol + (PW / 2) * h);
-                    blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
-                                                      store_any & (first <= 3 * PSTR), max(first, 0));
-                    // the slab is reused by the other half: this half's reads are complete (their values were consumed above)
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    continue;
+                        if (p * Win::RPP < nr && hact[h])
+                            __builtin_memcpy(&vh[h][p], gbase + (size_t)((uint32_t)min(p * Win::RPP, nr - Win::RPP) * pitch) + goff, sizeof(chunk_t));
+                } else {
+                    todo |= 1u << h;
                 }
             }
-            todo |= 1u << h;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                if (hrows[h] == 0) continue;                    // uniform
+#pragma unroll
+                for (int p = 0; p < Win::PASSES; ++p)
+                    if (p * Win::RPP < hrows[h] && hact[h]) {
+                        uint4 t4;
+                        if constexpr (CH == 4) {
+                            t4.x = vh[h][p].a; t4.y = vh[h][p].b; t4.z = vh[h][p].c; t4.w = vh[h][p].d;
+                        } else {
+                            t4.x = vh[h][p].a & 0xFFFFFFu;
+                            t4.y = __builtin_amdgcn_perm(vh[h][p].b, vh[h][p].a, 0x0C050403u);
+                            t4.z = __builtin_amdgcn_perm(vh[h][p].c, vh[h][p].b, 0x0C040302u);
+                            t4.w = vh[h][p].c >> 8;
+                        }
+                        *reinterpret_cast<uint4*>(my + (uint32_t)min(p * Win::RPP, hrows[h] - Win::RPP) * lpitch + wl) = t4;
+                    }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (h == 0) run_coords(0);                      // (run 1's coordinates are the ones in the registers right now)
+#pragma unroll
+                for (int j = 0; j < FP_PX; ++j) {
+                    weights2(lx[j], ly[j], WS, WO, WC, wx0[j], wx1[j], wy0[j], wy1[j]);
+                    const uint32_t lo = mad24_s(hy[j], lpitch, shl2_add_s(hx[j], 0u - tapc[h]));
+                    const uint32_t* t0 = reinterpret_cast<const uint32_t*>(slab0 + lo);
+                    const uint32_t* t1 = reinterpret_cast<const uint32_t*>(slab0 + lo + lpitch);
+                    a0[j] = t0[0]; b0[j] = t0[1]; a1[j] = t1[0]; b1[j] = t1[1];
+                }
+                const int first = tshift - (lcol + (PW / 2) * h);
+                blend_store<DstT, PSTR, CH, true>(a0, b0, a1, b1, wx0, wx1, wy0, wy1, drow + CH * (PW / 2) * h,
+                                                  store_any & (first <= 3 * PSTR), max(first, 0));
+                // the slab is reused by the other half: this half's reads are complete (their values were consumed above)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                if (h == 0 && hrows[1] != 0) run_coords(1);
+            }
         }
         if (todo == 0u) return;
     }
@@ -1198,11 +1234,15 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 template <typename DstT, int LOG_PW>
 __global__ __launch_bounds__(256, (f8_waves<DstT, LOG_PW>())) void warp_rgb8_fast8(const FastArgs a) { fast8_body<DstT, LOG_PW>(a, nullptr); }
 // minification (see HALVES above): the same kernel, windows per half patch
+// (round 4, both halves' staging loads in flight at once: 86 VGPRs for 64 x 8 patches -> 5 waves per SIMD, 102 for 32 x 16 -> 4; round 3's
+//  one-half-at-a-time form ran 6 with two exposed load latencies per wave)
+#ifndef RWH_F8H_WAVES
+#define RWH_F8H_WAVES(log_pw) ((log_pw) == 5 ? 4 : 5)
+#endif
 template <int LOG_PW>
-// (6 waves per SIMD for both shapes: at 7 the 64 x 8 form spills the destination pointer, and was 3 % slower in a same-box A/B)
-__global__ __launch_bounds__(256, 6) void warp_rgb8_fast8h(const FastArgs a) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, nullptr); }
+__global__ __launch_bounds__(256, RWH_F8H_WAVES(LOG_PW)) void warp_rgb8_fast8h(const FastArgs a) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, nullptr); }
 template <int LOG_PW>
-__global__ __launch_bounds__(256, 6) void warp_rgb8_fast8h_tab(const FastArgs a, const CoefTab t) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, t.e); }
+__global__ __launch_bounds__(256, RWH_F8H_WAVES(LOG_PW)) void warp_rgb8_fast8h_tab(const FastArgs a, const CoefTab t) { fast8_body<unsigned char, LOG_PW, false, 3, true>(a, t.e); }
 // RGBA uint8 in, RGBA uint8 out: 4-byte texels are slab texels as they lie in memory (no RGB -> RGBX expansion), a pixel is
 // one dword and a run one 16-byte store.  (The reference's own 4-channel images are float32: the generic kernel.)
 template <int LOG_PW>
@@ -2060,7 +2100,10 @@ inline bool patch_footprint(const FastArgs& a, double r, double c, int pw, int p
         xmin = x < xmin ? x : xmin; xmax = x > xmax ? x : xmax; ymin = y < ymin ? y : ymin; ymax = y > ymax ? y : ymax;
     }
     if (!(xmax - xmin < 1e6 && ymax - ymin < 1e6)) return false;
-    *rows = (long long)(ymax - ymin) + 2; *texels = (long long)(xmax - xmin) + 2;
+    // (the kernels' windows start on a multiple of 4 texels: up to 3 more columns.  Round 4 -- the whole-patch test used to ignore them, and at
+    //  1.3x minification the host chose whole 64 x 8 patches of which most then failed the device's test and gathered: 0.35 instead of 0.44)
+    const double xal = xmin >= 0 ? xmin - __builtin_fmod(xmin, 4.0) : xmin;
+    *rows = (long long)(ymax - ymin) + 2; *texels = (long long)(xmax - xal) + 2;
     *lines = (double)*rows * (3.0 * (double)*texels / 128.0 + 1.0);
     return true;
 }

@@ -7,7 +7,8 @@ if os.environ.get("RWH_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["RWH_LI
 from ransac_with_homography_amd.homography import _bounds
 dev = torch.device("cuda")
 H = np.array([[1.02, 0.01, 5.0], [0.015, 0.98, 7.0], [1e-5, 2e-5, 1.0]])
-B, SH, SW = 16, 2160, 3840
+torch.manual_seed(1)
+B, SH, SW = int(os.environ.get("FRAMES", "16")), 2160, 3840
 src = torch.randint(0, 256, (B, SH, SW, 3), dtype=torch.uint8, device=dev)
 mx, my, ow, oh = _bounds(SH, SW, H, 0)
 grid = kernels.Grid(mx, mx + ow - 1, ow, my, my + oh - 1, oh)
