@@ -544,6 +544,9 @@ int launch_fast(const WarpArgs& w, const double* ih, double x0, double step_x, d
         if (nb >= (1ull << 31) / 8) return false;
         a.nblocks = (unsigned)nb;
         a.cpx = (a.nblocks + 7u) / 8u;
+#ifdef RWH_XCD_CHUNK_LOG   // lab builds (rwh_warp_rgb8.h): the grid is a whole number of 8-chunk groups
+        a.cpx = (a.cpx + (1u << RWH_XCD_CHUNK_LOG) - 1u) >> RWH_XCD_CHUNK_LOG << RWH_XCD_CHUNK_LOG;
+#endif
         a.tiles_x_magic = div_magic(a.tiles_x, nb);
         a.tiles_y_magic = div_magic(a.tiles_y, nb / a.tiles_x + 1);
         return !((a.tiles_x > 1 && !a.tiles_x_magic) || (a.tiles_y > 1 && !a.tiles_y_magic));

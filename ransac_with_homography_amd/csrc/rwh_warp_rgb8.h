@@ -722,7 +722,12 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
     const unsigned b = blockIdx.x;
+#ifdef RWH_XCD_CHUNK_LOG   // lab builds: XCD k takes chunks of 2^LOG consecutive logical blocks round-robin (the product: ONE chunk of cpx blocks per XCD)
+    const unsigned logical = ovr_logical >= 0 ? (unsigned)ovr_logical
+                                              : (((b >> 3) >> RWH_XCD_CHUNK_LOG) << (RWH_XCD_CHUNK_LOG + 3)) + ((b & 7u) << RWH_XCD_CHUNK_LOG) + ((b >> 3) & ((1u << RWH_XCD_CHUNK_LOG) - 1u));
+#else
     const unsigned logical = ovr_logical >= 0 ? (unsigned)ovr_logical : (b & 7u) * a.cpx + (b >> 3);   // XCD k walks logical blocks [k*cpx, (k+1)*cpx)
+#endif
     const unsigned t = a.tiles_x_magic ? __umulhi(logical, a.tiles_x_magic) : logical;   // magic 0 <=> divisor 1
     const unsigned tx = logical - t * a.tiles_x;
     {   // a patch that owns nothing does nothing: a block past the grid, or a patch of the moved last tile of a ragged row
