@@ -335,9 +335,10 @@ def _parity_path_leg(self):
             with contextlib.redirect_stdout(io.StringIO()):
                 r = rs.RANSAC(rs.HomoModel(th=5, d=95, n=4), k=K)
                 return r, r.run([Xd, Yd], method="fwd")
-        run_d()
+        for _ in range(4):          # (a new problem size: page-locked workspace, allocator blocks and the host pool's threads settle in 3-4 calls)
+            run_d()
         ts = []
-        for _ in range(3):
+        for _ in range(7):
             t0 = time.perf_counter()
             r, (H, inl, cnt) = run_d()
             ts.append(time.perf_counter() - t0)
@@ -346,7 +347,7 @@ def _parity_path_leg(self):
         rep = int(((idx[:, 0] == idx[:, 1]) | (idx[:, 0] == idx[:, 2]) | (idx[:, 0] == idx[:, 3]) | (idx[:, 1] == idx[:, 2]) |
                    (idx[:, 1] == idx[:, 3]) | (idx[:, 2] == idx[:, 3])).sum())
         out.setdefault("dense_sets K=10000", {})[name] = {
-            "correspondences": M, "ms_per_run": round(sorted(ts)[1] * 1e3, 3), "inliers": int(cnt),
+            "correspondences": M, "ms_per_run": round(sorted(ts)[len(ts) // 2] * 1e3, 3), "inliers": int(cnt),
             "flagged_by_k1_share": round(lr.get("flagged", 0) / K, 4), "host_solved_share": round(lr.get("host_settled", 0) / K, 4),
             "repeated_index_share": round(rep / K, 4), "count_intervals": lr.get("intervals")}
     out["note"] = ("RANSAC.run: bit-exact inlier sets (tests: 19 reference runs + g10 + g12 + dense clouds vs the oracle).  The K=... entries beside "
