@@ -4,6 +4,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ransac_with_homography_amd import _lib, kernels
 from ransac_with_homography_amd import homography as hg
+if os.environ.get("RWH_LIB"): _lib.LIB_PATH = os.path.abspath(os.environ["RWH_LIB"])      # a lab build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 f = np.load(os.path.join(ROOT, "tests", "golden", "img_foto1.npz")); z = np.load(os.path.join(ROOT, "tests", "golden", "g8_stitch.npz"))
 dev = _lib.require_gpu()
