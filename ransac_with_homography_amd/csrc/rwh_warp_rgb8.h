@@ -718,7 +718,10 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     constexpr bool MX = CH == 3 && MIX_RGB;
     constexpr float WS = MX ? W_SCALE * MIX_S : W_SCALE, WO = MX ? W_ONE * MIX_S : W_ONE, WC = MX ? MIX_S : 1.0f;
     unsigned char* slab0;
-    if constexpr (EXT_SLAB) slab0 = slab_ext; else slab0 = wave_slabs<SLAB>();     // (slab_ext: the calling kernel's own, at least as large)
+    // slab_ext: THIS WAVE's slab inside the calling kernel's own array (at least SLAB bytes; the caller's per-wave stride may be larger than SLAB --
+    // round 4: the multi-frame kernel's is 5 168 B against 5 040 here, and indexing its array with this body's stride let a border wave's staging
+    // overwrite the end of its interior neighbour's window: tools/soak_mf.py, 3 % of random launches a few pixels off, never the same twice)
+    if constexpr (EXT_SLAB) slab0 = slab_ext; else slab0 = wave_slabs<SLAB>();
 
     // ---- block / wave -> patch (all scalar) ---------------------------------------------------------
     const unsigned b = blockIdx.x;
@@ -901,7 +904,8 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
     }
 
     // ---- staging loads go out now: lane -> (row srow of the pass, chunk scol), fixed for the kernel ---------------------
-    unsigned char* my = slab0 + pwave * SLAB;
+    const uint32_t slab_off_w = EXT_SLAB ? 0u : (uint32_t)pwave * (uint32_t)SLAB;      // this wave's slab inside slab0
+    unsigned char* my = slab0 + slab_off_w;
     using chunk_t = typename std::conditional<CH == 4, pk4, pk3>::type;   // 4 texels as they lie in memory: 12 or 16 bytes
     chunk_t v[Win::PASSES];
     // lanes outside the footprint (chunk >= C, or past the last full row of a pass) load nothing: the texture-address
@@ -936,7 +940,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
         // footprint origin and the slab's own LDS offset go into one uniform
         // (the multiply-add is spelled in assembly: given __umul24, LLVM distributes the subtraction and emits a
         //  quarter-rate v_mul_lo_u32 per tap)
-        const uint32_t slab_off = (uint32_t)pwave * (uint32_t)SLAB;
+        const uint32_t slab_off = slab_off_w;
         const uint32_t tap_c = ((uint32_t)hymn & 0xFFFFFFu) * lpitch + ((uint32_t)hxmn << 2) - slab_off;   // uniform
 #pragma unroll
         for (int p = 0; p < Win::PASSES; ++p) {
@@ -1133,7 +1137,7 @@ __device__ __forceinline__ void fast8_body(const FastArgs& a, const Coef* tab, c
                                    (nr >= Win::RPP) & (nr <= Win::ROWS) & (hC <= Win::LPRW);
                 hrows[h] = hfits ? nr : 0;
                 hact[h] = (srow < Win::RPP) & (scol < hC);
-                tapc[h] = ((uint32_t)qymn & 0xFFFFFFu) * lpitch + ((uint32_t)qxmn << 2) - (uint32_t)pwave * (uint32_t)SLAB;
+                tapc[h] = ((uint32_t)qymn & 0xFFFFFFu) * lpitch + ((uint32_t)qxmn << 2) - slab_off_w;
                 if (hfits) {
                     const unsigned char* gbase = simg + (size_t)((uint32_t)symn * pitch + (uint32_t)sxmn * (uint32_t)CH);   // uniform
 #pragma unroll
@@ -1407,7 +1411,8 @@ __device__ __forceinline__ void fast8m_body(const FastArgs& a) {
     const bool staged = wpos & (xmn >= 0) & (xmx < a.bound_w - 1) & (ymn >= 0) & (ymx < min(a.bound_h - 1, a.src_h - 2)) &
                         (nrows >= Win::RPP) & (nrows <= Win::ROWS) & (C <= Win::LPRW);
     if (!staged) {      // outside / border / gather patches: the one-frame body, frame by frame
-        for (int f = f0; f < f1; ++f) fast8_body<unsigned char, LOG_PW, false, 3, false, true>(a, nullptr, nullptr, (int)((unsigned)f * a.ntiles + ti), slab0);
+        for (int f = f0; f < f1; ++f)
+            fast8_body<unsigned char, LOG_PW, false, 3, false, true>(a, nullptr, nullptr, (int)((unsigned)f * a.ntiles + ti), slab0 + pwave * SLAB);
         return;
     }
 
@@ -1680,7 +1685,8 @@ __device__ __forceinline__ void fast8mb_body(const FastArgs& a) {
     if (!(all_in && nrows <= BROWS && C <= BCH)) {            // block-uniform: the one-frame body, frame by frame, every wave its patch
         const int own_from = (int)tx * 128 - min((int)tx * 128, a.out_w - 128);
         if ((wave % WX + 1) * PW <= own_from) return;
-        for (int f = f0; f < f1; ++f) fast8_body<unsigned char, LOG_PW, false, 3, false, true>(a, nullptr, nullptr, (int)((unsigned)f * a.ntiles + ti), slab0);
+        for (int f = f0; f < f1; ++f)
+            fast8_body<unsigned char, LOG_PW, false, 3, false, true>(a, nullptr, nullptr, (int)((unsigned)f * a.ntiles + ti), slab0 + wave * SLABW);
         return;
     }
 

@@ -1277,6 +1277,45 @@ def test_warp_multi_frame_equals_single(gpu, case, shape):
     assert (d > 1).sum() <= 9, (case, shape, int((d > 1).sum()))
 
 
+def test_warp_multi_frame_random_cases(gpu):
+    """Round 4 regression: 160 random launches (the generator of tools/soak_mf.py, seed 81) of both multi-frame lab kernels against the
+    one-frame kernel, bit for bit.  Before the fix a border wave that fell back to the one-frame body indexed the block's slab array with
+    THAT body's per-wave stride (5 040 B) inside the multi-frame kernel's 5 168 B slots and overwrote the end of its interior neighbour's
+    window: a few pixels on patch edges wrong in 3 % of such launches (cases 12, 47, 60, 80, 85, 99, 107, 128 of this stream), differently
+    every time -- the fixed-geometry test above never saw it."""
+    from ransac_with_homography_amd import kernels
+    rng = np.random.default_rng(81)
+    for case in range(160):
+        sh, sw = int(rng.integers(40, 900)), int(rng.integers(140, 1500))
+        nb = int(rng.integers(2, 12))
+        img = torch.randint(0, 256, (nb, sh, sw, 3), dtype=torch.uint8, device=gpu)
+        t = rng.uniform(-np.pi, np.pi) if case % 4 == 0 else rng.uniform(-0.08, 0.08)
+        sx, sy = rng.uniform(0.6, 1.6, 2) if case % 5 == 0 else rng.uniform(0.9, 1.15, 2)
+        A = np.array([[np.cos(t), -np.sin(t)], [np.sin(t), np.cos(t)]]) @ np.array([[sx, rng.uniform(-0.1, 0.1)], [0, sy]])
+        H = np.eye(3); H[:2, :2] = A
+        H[:2, 2] = rng.uniform(-60, 60, 2) + np.array([sw / 2, sh / 2]) - A @ np.array([sw / 2, sh / 2])
+        H[2, :2] = rng.uniform(-2e-4, 2e-4, 2) if case % 7 else rng.uniform(-2e-3, 2e-3, 2)
+        inv = np.linalg.inv(H)
+        ow, oh = int(rng.integers(128, 1900)), int(rng.integers(5, 1100))
+        x0, y0 = rng.uniform(-120, 60, 2)
+        stepx, stepy = rng.uniform(0.85, 1.2, 2)
+        grid = kernels.Grid(x0, x0 + stepx * (ow - 1), ow, y0, y0 + stepy * (oh - 1), oh)
+        bound = (sh, sw) if case % 4 else (int(rng.integers(sh // 2, sh + 1)), int(rng.integers(sw // 2, sw + 1)))
+        shape = int(rng.choice([0, 0, 5, 6, 7]))
+        rows = None if case % 3 else tuple(sorted(int(v) for v in rng.integers(0, oh + 1, 2)))
+        if rows is not None and rows[0] == rows[1]:
+            rows = None
+        ns = (int(rng.integers(2, 6)), 100 + int(rng.integers(2, 6)))
+        _force_shape(shape)
+        _force_frames(1)
+        ref = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.uint8, zero_origin=False, rows=rows)
+        for n in ns:
+            _force_frames(n)
+            for _ in range(2):          # (the race showed differently from launch to launch)
+                got = kernels.warp_backward(img, inv, grid, bound, "bilinear", torch.uint8, zero_origin=False, rows=rows)
+                assert torch.equal(got, ref), (case, shape, n, int((got != ref).sum()))
+
+
 @pytest.mark.parametrize("case", ["zoom1p4", "zoom1p6", "zoom2", "zoom2_rot3", "persp_zoom", "zoom3"])
 def test_warp_minification_halves(gpu, case, monkeypatch):
     """Minification: when no whole patch fits its staging window the host picks the kernel that stages a patch by halves

@@ -32,7 +32,7 @@ np.random.seed(0)
 _, idx32 = impl.legacy_randint_table(M, K, 4, want64=False)
 addr, gesv = _lapack.dgesdd_address(), _lapack.routine_address("dgesv")
 ws = kernels.RunWorkspace(M, K, dev)
-need, thr = kernels.need_count(M, 70, 4), impl._weak_threshold(5)
+need, thr = kernels.need_count(M, int(os.environ.get("D", "70")), 4), impl._weak_threshold(5)
 for th in [int(v) for v in os.environ.get("THREADS", "8,16,24,32,48,64").split(",")]:
     r = [None]
     def f():
@@ -44,7 +44,7 @@ rep = impl.repeated_rows(idx32)
 rows = np.ascontiguousarray(idx32[rep])
 for th in (8, 16, 32, 64):
     print("host SVD loop alone, %d samples, %2d threads: min %.3f median %.3f ms" % ((len(rows), th) + best_of(lambda: impl.svd_hypotheses(pa, pb, rows, threads=th))))
-r = rs.RANSAC(rs.HomoModel(th=5, d=70, n=4), k=K)
+r = rs.RANSAC(rs.HomoModel(th=5, d=int(os.environ.get("D", "70")), n=4), k=K)
 def whole():
     np.random.seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
