@@ -117,3 +117,40 @@ def test_plain_command_self_launches():
     assert p.returncode != 0                                   # no GPUs in this container
     assert "set_device" in log or "HIP" in log or "cuda" in log.lower(), log[-2000:]
     assert log.count("Traceback") >= 1 and "ChildFailedError" in log
+
+
+def test_counter_rows_of_the_committed_profile():
+    """bench.py attaches the committed PMC row to every other warp kernel of the line (round-3 verdict item 3: a limiter per kernel) and reads
+    the headline kernel's traffic / VALU-busy figure from the same file: the file must hold what those lookups expect."""
+    import json
+    import bench
+    doc = json.load(open(os.path.join(ROOT, bench.PMC_JSON)))
+    head = doc["rwh::warp_rgb8_fast8<unsigned char, 6>"]
+    assert tuple(head["src"]) == (3840, 2160) and head["frames"] == 32
+    assert 0.99 < head["hbm_bytes_per_launch"] / head["algorithmic_bytes_per_launch"] < 1.02          # no wasted HBM traffic
+    assert head["valu_busy_frac"] > 0.9 and "limiter" in head
+    for kernel in ("rwh::warp_rgb8_fast8<float, 6>", "rwh::warp_rgb8_nn<6>", "rwh::warp_rgb8_fast8h<6>", "rwh::warp_rgba8_fast8<6>",
+                   "rwh::warp_generic<float, 4, float, 1>"):
+        row = bench.pmc_row(kernel)["pmc"]
+        assert row["limiter"] and row["source"] == bench.PMC_JSON and 0.0 < row["valu_busy"] <= 1.05, kernel
+    assert bench.pmc_row("rwh::no_such_kernel") == {} and bench.pmc_row(None) == {}
+    facts = bench.profile_facts("rwh::warp_rgb8_fast8<unsigned char, 6>", 32, (3840, 2160), 0.372, 1950.0)
+    assert facts["traffic"] == head["hbm_bytes_per_launch"] and 0.85 < facts["valu"]["frac"] < 1.0
+    assert bench.profile_facts("rwh::warp_rgb8_fast8<unsigned char, 6>", 32, (1920, 1080), 0.372) == {}     # another source size: not the profiled launch
+
+
+def test_host_threads_follow_the_rank_share(monkeypatch):
+    """The settle step's LAPACK loop takes this process's share of the cores it may run on: one rank per GPU under torchrun."""
+    from ransac_with_homography_amd import ransac as impl
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(256)), raising=False)
+    monkeypatch.delenv("LOCAL_WORLD_SIZE", raising=False)
+    assert impl._host_thread_share() == 32
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert impl._host_thread_share() == 32
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(64)), raising=False)
+    assert impl._host_thread_share() == 8
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "nonsense")
+    assert impl._host_thread_share() == 32
+    monkeypatch.setattr(os, "sched_getaffinity", lambda pid: set(range(3)), raising=False)
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert impl._host_thread_share() == 1
